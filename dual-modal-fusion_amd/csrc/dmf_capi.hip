@@ -1,0 +1,312 @@
+// dmf_capi.hip — extern "C" entry points of libdmf_hip.so (declared in include/dmf.h) and the small
+// batch-level kernels around the fused patch kernel: slab/outer-product gradient reduction, fused Adam,
+// on-device confusion matrix / label map, pan2ms.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dmf.h"
+#include "dmf_shapes.h"
+
+namespace dmf {
+
+struct KArgs {   // must match dmf_patch_kernel.hip
+  dmf_input in;
+  const float* theta;
+  const float* pool;
+  const int32_t* labels;
+  const float* dlogits;
+  float loss_scale;
+  float* logits;
+  float* loss;
+  int32_t* pred;
+  float* slab;
+  float* ws_z;
+  float* ws_h;
+  float* ws_dh;
+  float* ws_dl;
+  int32_t K;
+};
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2 };
+
+int patch_shape_supported(const dmf_shape& s);
+hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, const char* detail) {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return 1;
+}
+static int check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return 1;
+}
+
+static Layout layout_of(const dmf_shape& s) { return make_layout(s.C, s.C2, s.P, s.S, s.F, s.G, s.H, s.K); }
+
+// ------------------------------------------------------------------------------ gradient reduction (+Adam)
+// One thread-row of 32 consecutive parameters x 8 batch chunks per 256-thread block; chunk partials are
+// combined through LDS in fixed order, so the result is independent of scheduling.
+//   conv params  : grad[p] = sum_blk slab[blk][p]
+//   fc1.weight   : grad = sum_b dh[b][j] * z[b][i]      fc1.bias: sum_b dh[b][j]
+//   fc2.weight   : grad = sum_b dl[b][k] * h[b][j]      fc2.bias: sum_b dl[b][k]
+struct ReduceArgs {
+  const float* slab; const float* z; const float* h; const float* dh; const float* dl;
+  int B, nblk, SLAB, NCONV, F2, H, K;
+  int64_t oFc1w, oFc1b, oFc2w, oFc2b, n;
+  float* grad;
+  float* theta; float* m; float* v;   // Adam (theta == nullptr: reduce only)
+  float lr, b1, b2, eps, bc1, bc2_sqrt;
+};
+
+__device__ __forceinline__ void adam_update(float* theta, float* m, float* v, int64_t p, float g,
+                                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  // torch.optim.Adam single-tensor path: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+  // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
+  const float mo = m[p], vo = v[p];
+  const float mn = mo + (g - mo) * (1.f - b1);
+  const float vn = vo * b2 + (1.f - b2) * g * g;
+  m[p] = mn;
+  v[p] = vn;
+  const float denom = sqrtf(vn) / bc2_sqrt + eps;
+  theta[p] -= (lr / bc1) * (mn / denom);
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
+  __shared__ float part[8][32];
+  const int jj = threadIdx.x & 31, ch = threadIdx.x >> 5;
+  const int64_t p = (int64_t)blockIdx.x * 32 + jj;
+  float acc = 0.f;
+  if (p < a.n) {
+    if (p < a.NCONV) {
+      const int per = (a.nblk + 7) / 8;
+      const int lo = ch * per, hi = min(a.nblk, lo + per);
+      for (int b = lo; b < hi; ++b) acc += a.slab[(size_t)b * a.SLAB + p];
+    } else {
+      const int per = (a.B + 7) / 8;
+      const int lo = ch * per, hi = min(a.B, lo + per);
+      if (p < a.oFc1b) {
+        const int q = (int)(p - a.oFc1w), j = q / a.F2, i = q - j * a.F2;
+        for (int b = lo; b < hi; ++b) acc = fmaf(a.dh[(size_t)b * a.H + j], a.z[(size_t)b * a.F2 + i], acc);
+      } else if (p < a.oFc2w) {
+        const int j = (int)(p - a.oFc1b);
+        for (int b = lo; b < hi; ++b) acc += a.dh[(size_t)b * a.H + j];
+      } else if (p < a.oFc2b) {
+        const int q = (int)(p - a.oFc2w), k = q / a.H, j = q - k * a.H;
+        for (int b = lo; b < hi; ++b) acc = fmaf(a.dl[(size_t)b * KMAX + k], a.h[(size_t)b * a.H + j], acc);
+      } else {
+        const int k = (int)(p - a.oFc2b);
+        for (int b = lo; b < hi; ++b) acc += a.dl[(size_t)b * KMAX + k];
+      }
+    }
+  }
+  part[ch][jj] = acc;
+  __syncthreads();
+  if (ch == 0 && p < a.n) {
+    const float g = ((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj])) +
+                    ((part[4][jj] + part[5][jj]) + (part[6][jj] + part[7][jj]));
+    if (a.grad != nullptr) a.grad[p] = g;
+    if (a.theta != nullptr) adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, a.bc1, a.bc2_sqrt);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* theta, const float* grad, float* m, float* v, int64_t n,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float grad_scale) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) adam_update(theta, m, v, p, grad[p] * grad_scale, lr, b1, b2, eps, bc1, bc2_sqrt);
+}
+
+// ------------------------------------------------------------------------------ eval helpers
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t* pred, const int32_t* target, int B, int K,
+                                                        unsigned long long* matrix) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) {
+    const int p = pred[i], t = target[i];
+    if (p >= 0 && p < K && t >= 0 && t < K) atomicAdd(&matrix[(size_t)p * K + t], 1ull);   // rows = prediction
+  }
+}
+
+__global__ __launch_bounds__(256) void labelmap_kernel(const int32_t* pred, const int32_t* xy, int B, int W, int32_t* map) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) map[(size_t)xy[2 * i] * W + xy[2 * i + 1]] = pred[i];
+}
+
+// pan2ms (image_convert/IHS.py:14-19): p = 2x2 mean pool of pan; out[:, :, i] = p[i%2::2, i//2::2]
+//   => out[h, w, i] = mean(pan[4h + 2(i%2) + {0,1}, 4w + 2(i//2) + {0,1}])
+__global__ __launch_bounds__(256) void pan2ms_kernel(const double* pan, int pitch, int H, int W, double* out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)H * W * 4) return;
+  const int i = (int)(e & 3);
+  const int64_t hw = e >> 2;
+  const int h = (int)(hw / W), w = (int)(hw - (int64_t)h * W);
+  const int r = 4 * h + 2 * (i % 2), c = 4 * w + 2 * (i / 2);
+  const double* p0 = pan + (size_t)r * pitch + c;
+  // numpy.mean over a 2x2 block: running sum in row-major order, then / 4
+  out[e] = (((p0[0] + p0[1]) + p0[pitch]) + p0[pitch + 1]) / 4.0;
+}
+
+}  // namespace dmf
+
+using namespace dmf;
+
+extern "C" {
+
+int32_t dmf_version(void) { return DMF_VERSION; }
+const char* dmf_last_error(void) { return g_err; }
+
+int32_t dmf_shape_supported(const dmf_shape* s) {
+  if (s == nullptr) return fail("%s", "null shape");
+  if (!patch_shape_supported(*s)) {
+    snprintf(g_err, sizeof(g_err),
+             "no compiled kernel instance for C=%d C2=%d P=%d S=%d F=%d G=%d H=%d K=%d attention=%d "
+             "(instances: dmf_patch_kernel.hip, 'Compiled instances')",
+             s->C, s->C2, s->P, s->S, s->F, s->G, s->H, s->K, s->attention);
+    return 1;
+  }
+  return 0;
+}
+
+int32_t dmf_param_layout(const dmf_shape* s, int64_t offsets[17]) {
+  if (s == nullptr || offsets == nullptr) return fail("%s", "null argument");
+  const Layout L = layout_of(*s);
+  for (int i = 0; i < 17; ++i) offsets[i] = L.off[i];
+  return 0;
+}
+
+int64_t dmf_workspace_bytes(const dmf_shape* s, int32_t B) {
+  if (s == nullptr || B < 0) return -1;
+  const Layout L = layout_of(*s);
+  return make_ws(L, B).total * 4;
+}
+
+static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const float* theta, const float* pool_w,
+                     const int32_t* labels, const float* dlogits, float loss_scale, float* logits, float* loss,
+                     int32_t* pred, void* workspace, void* stream) {
+  if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr) return fail("%s", "null argument");
+  if (dmf_shape_supported(s)) return 1;
+  if (in->B < 0) return fail("%s", "negative batch");
+  if (in->B == 0) return 0;
+  if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");
+  if (in->mode == 1 && (in->sceneA == nullptr || in->sceneB == nullptr || in->xy == nullptr || in->Wp <= 0 || in->WpB <= 0))
+    return fail("%s", "mode 1 needs sceneA, sceneB, xy, Wp, WpB");
+  if (in->mode != 0 && in->mode != 1) return fail("%s", "input mode must be 0 or 1");
+  KArgs a{};
+  a.in = *in;
+  a.theta = theta;
+  a.pool = pool_w;
+  a.labels = labels;
+  a.dlogits = dlogits;
+  a.loss_scale = loss_scale;
+  a.logits = logits;
+  a.loss = loss;
+  a.pred = pred;
+  a.K = s->K;
+  if (mode != MODE_FWD) {
+    if (workspace == nullptr) return fail("%s", "null workspace");
+    const Layout L = layout_of(*s);
+    const WsLayout w = make_ws(L, in->B);
+    float* ws = static_cast<float*>(workspace);
+    a.slab = ws + w.slab;
+    a.ws_z = ws + w.z;
+    a.ws_h = ws + w.h;
+    a.ws_dh = ws + w.dh;
+    a.ws_dl = ws + w.dl;
+  }
+  return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
+}
+
+int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                    float* logits, int32_t* pred, void* stream) {
+  if (logits == nullptr) return fail("%s", "null logits");
+  return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, stream);
+}
+
+int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                          const int32_t* labels, float loss_scale, float* logits, float* loss, void* workspace,
+                          void* stream) {
+  if (labels == nullptr || logits == nullptr || loss == nullptr) return fail("%s", "null labels/logits/loss");
+  return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, stream);
+}
+
+int32_t dmf_backward_dlogits(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                             const float* dlogits, void* workspace, void* stream) {
+  if (dlogits == nullptr) return fail("%s", "null dlogits");
+  return run_patch(s, in, MODE_BWD, theta, pool_w, nullptr, dlogits, 1.f, nullptr, nullptr, nullptr, workspace, stream);
+}
+
+static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, float* theta, float* m,
+                      float* v, float lr, float b1, float b2, float eps, int32_t step, void* stream) {
+  if (s == nullptr || workspace == nullptr) return fail("%s", "null argument");
+  if (B <= 0) return fail("%s", "batch must be positive");
+  const Layout L = layout_of(*s);
+  const WsLayout w = make_ws(L, B);
+  const float* ws = static_cast<const float*>(workspace);
+  ReduceArgs a{};
+  a.slab = ws + w.slab; a.z = ws + w.z; a.h = ws + w.h; a.dh = ws + w.dh; a.dl = ws + w.dl;
+  a.B = B; a.nblk = B < MAX_BLOCKS ? B : MAX_BLOCKS; a.SLAB = L.SLAB; a.NCONV = L.NCONV; a.F2 = L.F2; a.H = L.H; a.K = L.K;
+  a.oFc1w = L.off[8]; a.oFc1b = L.off[9]; a.oFc2w = L.off[10]; a.oFc2b = L.off[11]; a.n = L.n_params;
+  a.grad = grad; a.theta = theta; a.m = m; a.v = v;
+  a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps;
+  if (theta != nullptr) {
+    if (m == nullptr || v == nullptr || step < 1) return fail("%s", "Adam needs m, v and step >= 1");
+    a.bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  }
+  const int grid = (int)((L.n_params + 31) / 32);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return check(hipGetLastError(), "grad_reduce launch");
+}
+
+int32_t dmf_grad_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, void* stream) {
+  if (grad == nullptr) return fail("%s", "null grad");
+  return run_reduce(s, B, workspace, grad, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0, stream);
+}
+
+int32_t dmf_grad_reduce_adam(const dmf_shape* s, int32_t B, const void* workspace, float* theta, float* m, float* v,
+                             float* grad, float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  if (theta == nullptr) return fail("%s", "null theta");
+  return run_reduce(s, B, workspace, grad, theta, m, v, lr, beta1, beta2, eps, step, stream);
+}
+
+int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+  if (theta == nullptr || grad == nullptr || m == nullptr || v == nullptr) return fail("%s", "null argument");
+  if (n <= 0 || step < 1) return fail("%s", "n and step must be positive");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     theta, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+  return check(hipGetLastError(), "adam launch");
+}
+
+int32_t dmf_confusion_accum(const int32_t* pred, const int32_t* target, int32_t B, int32_t K, int64_t* matrix, void* stream) {
+  if (pred == nullptr || target == nullptr || matrix == nullptr) return fail("%s", "null argument");
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(confusion_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), pred,
+                     target, B, K, reinterpret_cast<unsigned long long*>(matrix));
+  return check(hipGetLastError(), "confusion launch");
+}
+
+int32_t dmf_labelmap_write(const int32_t* pred, const int32_t* xy, int32_t B, int32_t W, int32_t* map, void* stream) {
+  if (pred == nullptr || xy == nullptr || map == nullptr) return fail("%s", "null argument");
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(labelmap_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), pred, xy,
+                     B, W, map);
+  return check(hipGetLastError(), "labelmap launch");
+}
+
+int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, double* out, void* stream) {
+  if (pan == nullptr || out == nullptr) return fail("%s", "null argument");
+  if (H <= 0 || W <= 0 || pitch < 4 * W) return fail("%s", "bad pan2ms geometry");
+  const int64_t n = (int64_t)H * W * 4;
+  hipLaunchKernelGGL(pan2ms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     pan, pitch, H, W, out);
+  return check(hipGetLastError(), "pan2ms launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Compile-time geometry of one GMFNet instance + the flat parameter / workspace layouts shared by
+// host and device code.  (The architecture itself is stated in oracle/gmfnet_ref.py and DESIGN.md §2.)
+#pragma once
+#include <stdint.h>
+
+namespace dmf {
+
+constexpr int MAX_BLOCKS = 256;    // one workgroup per CU; a workgroup walks patches b, b+grid, ...
+constexpr int KMAX = 64;
+
+template <int C_, int C2_, int P_, int S_, int F_, int G_, int H_>
+struct Shape {
+  static constexpr int C = C_, C2 = C2_, P = P_, S = S_, F = F_, G = G_, H = H_;
+  static constexpr int P2 = P * P;          // pixels (tokens) per patch
+  static constexpr int Cg = C / G;          // bands per spectral group
+  static constexpr int M = F / G;           // outputs per spectral group
+  static constexpr int SP = S * P;          // aux patch side
+  static constexpr int PB = SP * SP;        // aux pixels per patch
+  static constexpr int TB = C2 * S * S;     // taps of the lift conv
+  static constexpr int F2 = 2 * F;
+  // threads per workgroup: 8 wave64 (2 per SIMD; one workgroup per CU), more only when a patch has
+  // more than 512 (channel,row) pairs
+  static constexpr int NT = (F * P <= 512) ? 512 : ((F * P + 63) / 64) * 64;
+  static constexpr int NW = NT / 64;
+  // LDS row strides (floats).  (Cs/4) odd makes a 16-lane ds_read_b128 group with lane<->pixel hit 64
+  // distinct banks (MI355X_MICROARCH.md §LDS); Y1 rows are read lane<->channel, so they need no pad.
+  static constexpr int Cs = C + ((((C / 4) & 1) == 0) ? 4 : 0);
+  static constexpr int Fs = F;
+  // flat parameter offsets (floats) — order documented in include/dmf.h
+  static constexpr int oA1w = 0;
+  static constexpr int oA1b = oA1w + F * Cg;
+  static constexpr int oA2w = oA1b + F;
+  static constexpr int oA2b = oA2w + F * 9;
+  static constexpr int oB1w = oA2b + F;
+  static constexpr int oB1b = oB1w + F * TB;
+  static constexpr int oB2w = oB1b + F;
+  static constexpr int oB2b = oB2w + F * 9;
+  static constexpr int NCONV = oB2b + F;    // conv parameters: reduced through per-workgroup slabs
+  static constexpr int oFc1w = NCONV;
+  static constexpr int oFc1b = oFc1w + H * F2;
+  static constexpr int oFc2w = oFc1b + H;   // [K, H], K is a run-time value
+  static constexpr int SLAB = (NCONV + 31) & ~31;   // slab row pitch (floats)
+
+  static_assert(C % G == 0 && F % G == 0, "groups must divide C and F");
+  static_assert(Cg % 4 == 0, "bands per group must be a multiple of 4 (16-byte chunks)");
+  static_assert(F % 4 == 0, "feature width must be a multiple of 4");
+  static_assert(P <= 32, "row masks are 32-bit");
+  static_assert(F * P <= NT && NT <= 1024, "one thread per (channel,row)");
+  static_assert(H * 8 <= NT && H <= 64 && 4 * F2 <= NT, "head mapping");
+};
+
+// run-time mirror of the layout (host side + generic kernels)
+struct Layout {
+  int C, C2, P, S, F, G, H, K;
+  int Cg, TB, F2, NCONV, SLAB;
+  int64_t off[17];
+  int64_t n_params;
+};
+
+inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int K) {
+  Layout L{};
+  L.C = C; L.C2 = C2; L.P = P; L.S = S; L.F = F; L.G = G; L.H = H; L.K = K;
+  L.Cg = C / G; L.TB = C2 * S * S; L.F2 = 2 * F;
+  int64_t o = 0;
+  const int64_t sizes[12] = {(int64_t)F * L.Cg, F, (int64_t)F * 9, F, (int64_t)F * L.TB, F, (int64_t)F * 9, F,
+                             (int64_t)H * L.F2, H, (int64_t)K * H, K};
+  for (int i = 0; i < 12; ++i) { L.off[i] = o; o += sizes[i]; }
+  for (int i = 12; i < 17; ++i) L.off[i] = o;
+  L.NCONV = (int)L.off[8];
+  L.SLAB = (L.NCONV + 31) & ~31;
+  L.n_params = o;
+  return L;
+}
+
+// workspace layout (floats): [slab MAX_BLOCKS x SLAB][z B x 2F][h B x H][dh B x H][dl B x KMAX]
+struct WsLayout { int64_t slab, z, h, dh, dl, total; };
+inline WsLayout make_ws(const Layout& L, int B) {
+  WsLayout w{};
+  int64_t o = 0;
+  w.slab = o; o += (int64_t)MAX_BLOCKS * L.SLAB;
+  w.z = o;    o += (int64_t)B * L.F2;
+  w.h = o;    o += (int64_t)B * L.H;
+  w.dh = o;   o += (int64_t)B * L.H;
+  w.dl = o;   o += (int64_t)B * KMAX;
+  w.total = o;
+  return w;
+}
+
+}  // namespace dmf

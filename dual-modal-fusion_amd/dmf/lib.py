@@ -1,0 +1,174 @@
+"""ctypes binding of libdmf_hip.so (include/dmf.h).  PyTorch is used only for device memory and streams.
+
+The library is mandatory: importing this module without the built .so raises (there is NO CPU fallback —
+the CPU statement of the arithmetic lives under oracle/ and is test infrastructure only).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdmf_hip.so')
+KMAX = 64
+
+
+class DmfError(RuntimeError):
+    pass
+
+
+class Shape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('C', 'C2', 'P', 'S', 'F', 'G', 'H', 'K', 'attention', 'heads', 'E', 'reserved')]
+
+
+class Input(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('a', C.c_void_p), ('b', C.c_void_p), ('sceneA', C.c_void_p),
+                ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise DmfError('libdmf_hip.so is not built: run `python dual-modal-fusion_amd/build.py` '
+                       '(hipcc --offload-arch=gfx950); there is no CPU fallback for the product path')
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    SP, IP = C.POINTER(Shape), C.POINTER(Input)
+    protos = {
+        'dmf_version': (i32, []),
+        'dmf_last_error': (C.c_char_p, []),
+        'dmf_shape_supported': (i32, [SP]),
+        'dmf_param_layout': (i32, [SP, C.POINTER(i64)]),
+        'dmf_workspace_bytes': (i64, [SP, i32]),
+        'dmf_forward': (i32, [SP, IP, vp, vp, vp, vp, vp]),
+        'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp]),
+        'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
+        'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
+        'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
+        'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]),
+        'dmf_confusion_accum': (i32, [vp, vp, i32, i32, vp, vp]),
+        'dmf_labelmap_write': (i32, [vp, vp, i32, i32, vp, vp]),
+        'dmf_pan2ms': (i32, [vp, i32, i32, i32, vp, vp]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)       # AttributeError here = header and library disagree
+        fn.restype, fn.argtypes = res, args
+    return lib, tuple(protos)
+
+
+_lib, EXPORTS = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise DmfError(_lib.dmf_last_error().decode() or 'libdmf_hip error %d' % rc)
+
+
+def version():
+    return _lib.dmf_version()
+
+
+def make_shape(arch):
+    return Shape(C=arch['C'], C2=arch['C2'], P=arch['P'], S=arch['S'], F=arch['F'], G=arch['G'], H=arch['H'],
+                 K=arch['K'], attention=arch.get('attention', 0), heads=arch.get('heads', 0), E=arch.get('E', 0), reserved=0)
+
+
+def shape_supported(shape):
+    check(_lib.dmf_shape_supported(C.byref(shape)))
+
+
+def param_layout(shape):
+    off = (C.c_int64 * 17)()
+    check(_lib.dmf_param_layout(C.byref(shape), off))
+    return list(off)
+
+
+def workspace_bytes(shape, B):
+    n = _lib.dmf_workspace_bytes(C.byref(shape), B)
+    if n < 0:
+        raise DmfError('dmf_workspace_bytes failed')
+    return n
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise DmfError('%s must be a contiguous %s tensor on the GPU' % (name, dtype))
+    return t
+
+
+def input_patches(shape, a, b):
+    """mode 0: the reference dataloader's tensors, a [B,C,P,P], b [B,C2,SP,SP] (dataset.py:168-185)."""
+    _dev(a, torch.float32, 'a'); _dev(b, torch.float32, 'b')
+    B = a.shape[0]
+    SP = shape.S * shape.P
+    if tuple(a.shape) != (B, shape.C, shape.P, shape.P) or tuple(b.shape) != (B, shape.C2, SP, SP):
+        raise DmfError('patch tensors %s / %s do not match shape C=%d P=%d C2=%d S=%d' %
+                       (tuple(a.shape), tuple(b.shape), shape.C, shape.P, shape.C2, shape.S))
+    return Input(mode=0, B=B, a=a.data_ptr(), b=b.data_ptr(), sceneA=None, sceneB=None, xy=None, Wp=0, WpB=0)
+
+
+def input_gather(shape, sceneA, sceneB, xy):
+    """mode 1: sceneA [Hp,Wp,C], sceneB [HpB,WpB,C2] resident padded scenes, xy [B,2] int32 top-left pixels."""
+    _dev(sceneA, torch.float32, 'sceneA'); _dev(sceneB, torch.float32, 'sceneB'); _dev(xy, torch.int32, 'xy')
+    if sceneA.dim() != 3 or sceneA.shape[2] != shape.C or sceneB.dim() != 3 or sceneB.shape[2] != shape.C2:
+        raise DmfError('scene tensors must be [Hp,Wp,C] and [HpB,WpB,C2]')
+    if xy.dim() != 2 or xy.shape[1] != 2:
+        raise DmfError('xy must be [B,2]')
+    return Input(mode=1, B=xy.shape[0], a=None, b=None, sceneA=sceneA.data_ptr(), sceneB=sceneB.data_ptr(),
+                 xy=xy.data_ptr(), Wp=sceneA.shape[1], WpB=sceneB.shape[1])
+
+
+def check_xy_bounds(shape, sceneA, sceneB, xy_host):
+    """Host-side guard (a faulting gather can reset the GPU): every patch window must lie inside the scenes."""
+    if len(xy_host) == 0:
+        return
+    x_max, y_max = int(xy_host[:, 0].max()), int(xy_host[:, 1].max())
+    if int(xy_host.min()) < 0 or x_max + shape.P > sceneA.shape[0] or y_max + shape.P > sceneA.shape[1] or \
+            shape.S * (x_max + shape.P) > sceneB.shape[0] or shape.S * (y_max + shape.P) > sceneB.shape[1]:
+        raise DmfError('patch window outside the padded scene')
+
+
+def forward(shape, inp, theta, pool_w, logits, pred=None):
+    check(_lib.dmf_forward(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(logits), _ptr(pred), _stream()))
+
+
+def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws):
+    check(_lib.dmf_train_fwd_bwd(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels),
+                                 C.c_float(loss_scale), _ptr(logits), _ptr(loss), _ptr(ws), _stream()))
+
+
+def backward_dlogits(shape, inp, theta, pool_w, dlogits, ws):
+    check(_lib.dmf_backward_dlogits(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(dlogits), _ptr(ws), _stream()))
+
+
+def grad_reduce(shape, B, ws, grad):
+    check(_lib.dmf_grad_reduce(C.byref(shape), B, _ptr(ws), _ptr(grad), _stream()))
+
+
+def adam_step(theta, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    check(_lib.dmf_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), lr, b1, b2, eps, step,
+                             grad_scale, _stream()))
+
+
+def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step):
+    check(_lib.dmf_grad_reduce_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), _ptr(grad),
+                                    lr, b1, b2, eps, step, _stream()))
+
+
+def confusion_accum(pred, target, K, matrix):
+    check(_lib.dmf_confusion_accum(_ptr(pred), _ptr(target), pred.numel(), K, _ptr(matrix), _stream()))
+
+
+def labelmap_write(pred, xy, W, label_map):
+    check(_lib.dmf_labelmap_write(_ptr(pred), _ptr(xy), pred.numel(), W, _ptr(label_map), _stream()))
+
+
+def pan2ms(pan, H, W, out):
+    check(_lib.dmf_pan2ms(_ptr(pan), pan.shape[1], H, W, _ptr(out), _stream()))

@@ -1,0 +1,124 @@
+/*
+ * dmf.h — C ABI of the MI355X-native dual-modal fusion hot path (libdmf_hip.so).
+ *
+ * The reference (salalalala23/Dual-modal-fusion) is pure Python and defines NO FFI: its plug-in boundary
+ * is the model loader `importlib.import_module('model.' + net_name).Net(args=cfg)`
+ * (solver/mainsolver.py:31-34) whose product is called as `net(ms, pan)` (mainsolver.py:52) and trained by
+ * `CrossEntropyLoss` + `loss.backward()` + `Adam.step()` (mainsolver.py:49-55).  This library sits one level
+ * below that boundary: dual-modal-fusion_amd/model/gmfnet.py::Net binds these entry points with ctypes
+ * (INTEGRATION.md shows the stub).  Each entry point names the reference call site it replaces.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (text via dmf_last_error());
+ * all pointers except `shape`/`in` are DEVICE pointers owned by the caller; no allocation and no host
+ * synchronisation inside; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef DMF_H
+#define DMF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMF_VERSION 100   /* 0.1.0 */
+#define DMF_KMAX 64       /* max number of logits (Categories_Number, utils/config.py:25) */
+
+/* Network / patch geometry (oracle/gmfnet_ref.py::arch_from_cfg). */
+typedef struct dmf_shape {
+  int32_t C;    /* primary bands           (DATA_DICT[city].size[2], config.yml:77-80)          */
+  int32_t C2;   /* auxiliary bands                                                               */
+  int32_t P;    /* patch_size              (config.yml:27)                                       */
+  int32_t S;    /* aux / primary resolution ratio (reference hard-codes 4, dataset.py:166)       */
+  int32_t F;    /* feature width                                                                 */
+  int32_t G;    /* spectral groups                                                               */
+  int32_t H;    /* hidden width of the head                                                      */
+  int32_t K;    /* Categories_Number (logits), <= DMF_KMAX                                       */
+  int32_t attention;   /* 0 = late fusion only, 1 = cross-modal attention block                  */
+  int32_t heads;       /* attention heads (config.yml:70), head_dim = E / heads                  */
+  int32_t E;           /* attention embed dim (config.yml:69)                                    */
+  int32_t reserved;
+} dmf_shape;
+
+/* Where a batch of patches comes from. */
+typedef struct dmf_input {
+  int32_t mode;        /* 0: materialised patches (the reference dataloader's tensors, dataset.py:168-185)
+                          1: gather from the resident padded scene by pixel coordinates            */
+  int32_t B;           /* patches in this batch                                                    */
+  /* mode 0 */
+  const float* a;      /* [B, C, P, P]        band-major patches                                   */
+  const float* b;      /* [B, C2, S*P, S*P]                                                        */
+  /* mode 1 */
+  const float* sceneA; /* [Hp, Wp, C]   padded, normalised primary scene, pixel-major (function.py:99-117) */
+  const float* sceneB; /* [HpB, WpB, C2] padded aux scene                                          */
+  const int32_t* xy;   /* [B, 2] top-left pixel (x = row, y = col) of each patch (dataset.py:171-172) */
+  int32_t Wp;          /* row pitch of sceneA in pixels                                            */
+  int32_t WpB;         /* row pitch of sceneB in pixels                                            */
+} dmf_input;
+
+int32_t dmf_version(void);
+const char* dmf_last_error(void);
+
+/* 0 if a compiled kernel instance exists for this shape. */
+int32_t dmf_shape_supported(const dmf_shape* shape);
+
+/* Flat parameter vector theta (fp32).  Tensor order and offsets (in floats):
+ *   0 spec_a.weight [F, C/G]   1 spec_a.bias [F]   2 spat_a.weight [F, 9]   3 spat_a.bias [F]
+ *   4 lift_b.weight [F, C2*S*S] 5 lift_b.bias [F]  6 spat_b.weight [F, 9]   7 spat_b.bias [F]
+ *   8 fc1.weight [H, 2F]       9 fc1.bias [H]     10 fc2.weight [K, H]     11 fc2.bias [K]
+ *  12 attn_wq [E, F]  13 attn_wk [E, F]  14 attn_wv [E, F]  15 attn_wo [F, E]   (attention only)
+ * offsets[i] = start of tensor i, offsets[16] = total count. */
+int32_t dmf_param_layout(const dmf_shape* shape, int64_t offsets[17]);
+
+/* Bytes of scratch the train/backward entry points need for a batch of B patches. */
+int64_t dmf_workspace_bytes(const dmf_shape* shape, int32_t B);
+
+/* `pool_w` [P*P] is the network's fixed pooling profile (buffer `pool_w` of the Net).
+ *
+ * Replaces `output = self.cur_model(data1, data2)` in eval (mainsolver.py:109,169,180) and
+ * `pred = output.data.max(1)` (mainsolver.py:139,170).  logits [B, K]; pred [B] int32 may be NULL. */
+int32_t dmf_forward(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                    float* logits, int32_t* pred, void* stream);
+
+/* Replaces forward + `self.loss(output, target.long())` + `loss.backward()` (mainsolver.py:52-54) in ONE
+ * launch.  labels [B] int32.  loss_scale multiplies dlogits (1/B for CrossEntropyLoss' mean reduction,
+ * utils/utils.py:29).  Writes logits [B, K] and per-patch CE loss [B] (unscaled); leaves per-block weight-
+ * gradient slabs and head vectors in `workspace` for dmf_grad_reduce*. */
+int32_t dmf_train_fwd_bwd(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                          const int32_t* labels, float loss_scale,
+                          float* logits, float* loss, void* workspace, void* stream);
+
+/* Backward for a caller-supplied dL/dlogits [B, K] (the autograd path: torch computes the loss). */
+int32_t dmf_backward_dlogits(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                             const float* dlogits, void* workspace, void* stream);
+
+/* Workspace -> flat gradient [n_params] (deterministic fixed-order sums). */
+int32_t dmf_grad_reduce(const dmf_shape* shape, int32_t B, const void* workspace, float* grad, void* stream);
+
+/* Replaces `self.optimizer.step()` for torch.optim.Adam(lr) defaults (utils/utils.py:10-12;
+ * betas 0.9/0.999, eps 1e-8, no weight decay).  step = 1-based step count.  grad_scale multiplies grad
+ * first (1/world_size after an all-reduce(sum)). */
+int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n,
+                      float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
+/* dmf_grad_reduce + dmf_adam_step in one launch (single-GPU step). grad may be NULL. */
+int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* workspace,
+                             float* theta, float* m, float* v, float* grad,
+                             float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* Replaces the per-sample `.item()` loop `test_matrix[pred][target] += 1` (mainsolver.py:140-141):
+ * matrix [K, K] int64, rows = prediction. */
+int32_t dmf_confusion_accum(const int32_t* pred, const int32_t* target, int32_t B, int32_t K,
+                            int64_t* matrix, void* stream);
+
+/* Replaces `label_np[x][y] = pred` (mainsolver.py:171-173,182-183): map [H, W] int32. */
+int32_t dmf_labelmap_write(const int32_t* pred, const int32_t* xy, int32_t B, int32_t W, int32_t* map, void* stream);
+
+/* Replaces image_convert/IHS.py:14-19 `pan2ms` (2x2 mean pool + 2x2 polyphase split) for out [H, W, 4]
+ * from pan [>=4H, >=4W] with row pitch `pitch` floats; computed in fp64 like the reference. */
+int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMF_H */

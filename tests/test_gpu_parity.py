@@ -1,0 +1,265 @@
+"""GPU parity: the HIP path (through the C ABI, dmf/lib.py) against the CPU oracle (oracle/gmfnet_ref.py).
+
+Tolerances (fp32, BASELINE.json north_star): logits <= 1e-5 absolute; gradients <= 1e-5 absolute +
+1e-4 relative (different but fixed summation orders over 121 pixels x B patches).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (C, C2, P, S, K)
+    'tiny': (8, 1, 5, 4, 5),
+    'tiny1': (8, 1, 5, 1, 5),
+    'hsi': (200, 1, 11, 1, 17),
+    'hsi224': (224, 3, 11, 1, 17),
+    'panms': (4, 1, 16, 4, 12),
+}
+
+
+def make_cfg(name):
+    C, C2, P, S, K = SHAPES[name]
+    return {'patch_size': P, 'Categories_Number': K, 'data_city': 's', 'DATA_DICT': {'s': {'size': [64, 64, C]}},
+            'scale': S, 'aux_bands': C2, 'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+
+
+def nets(name, seed=0):
+    from oracle.gmfnet_ref import Net as RefNet
+    from model.gmfnet import Net as HipNet
+    cfg = make_cfg(name)
+    torch.manual_seed(seed)
+    ref = RefNet(cfg)
+    # make biases / weights less symmetric than the default init so every path carries signal
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    hip = HipNet(cfg)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to('cuda:0')
+    return cfg, ref, hip
+
+
+def rand_batch(name, B, seed=1):
+    C, C2, P, S, K = SHAPES[name]
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(B, C, P, P, generator=g)
+    b = torch.rand(B, C2, S * P, S * P, generator=g)
+    t = torch.randint(0, K, (B,), generator=g)
+    return a, b, t
+
+
+def ref_grads(ref, a, b, t, scale=None):
+    ref.zero_grad()
+    logits = ref(a, b)
+    loss = torch.nn.functional.cross_entropy(logits, t)
+    loss.backward()
+    return logits.detach(), loss.item(), {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+
+
+def assert_close(got, want, atol, rtol, what):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = err > tol
+    assert not bad.any(), '%s: %d/%d out of tolerance, max abs err %.3e (|ref| max %.3e) at %s' % (
+        what, int(bad.sum()), bad.numel(), err.max().item(), want.abs().max().item(),
+        np.unravel_index(int(err.argmax()), tuple(err.shape)) if err.dim() else ())
+
+
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+@pytest.mark.parametrize('B', [1, 37, 300])
+def test_forward_patches(name, B):
+    if name in ('hsi224', 'panms') and B == 300:
+        B = 260
+    cfg, ref, hip = nets(name)
+    a, b, t = rand_batch(name, B)
+    with torch.no_grad():
+        want = ref(a, b)
+        got = hip(a.cuda(), b.cuda())
+    assert got.shape == (B, SHAPES[name][4])
+    assert_close(got, want, 1e-5, 0, 'logits[%s,B=%d]' % (name, B))
+
+
+def _scene(name, H=23, W=19, seed=5):
+    C, C2, P, S, K = SHAPES[name]
+    g = torch.Generator().manual_seed(seed)
+    A = torch.rand(H + P - 1, W + P - 1, C, generator=g)
+    Bm = torch.rand(S * (H + P - 1), S * (W + P - 1), C2, generator=g)
+    return A, Bm
+
+
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+def test_forward_gather_and_pred(name):
+    from dmf import lib
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    H, W = 23, 19
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(2)
+    Bn = 301
+    xy = torch.stack([torch.randint(0, H, (Bn,), generator=g), torch.randint(0, W, (Bn,), generator=g)], 1).int()
+    xy[0] = torch.tensor([0, 0]); xy[1] = torch.tensor([H - 1, W - 1])          # extremes of the padded scene
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    b = torch.stack([Bm[S * x:S * x + S * P, S * y:S * y + S * P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    with torch.no_grad():
+        want = ref(a, b)
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    lib.check_xy_bounds(hip.shape, Ad, Bd, xy.numpy())
+    inp = lib.input_gather(hip.shape, Ad, Bd, xyd)
+    logits = torch.empty(Bn, K, device='cuda')
+    pred = torch.empty(Bn, dtype=torch.int32, device='cuda')
+    lib.forward(hip.shape, inp, hip.flat_parameters(), hip.pool_w, logits, pred)
+    assert_close(logits, want, 1e-5, 0, 'gather logits[%s]' % name)
+    assert torch.equal(pred.cpu().long(), logits.cpu().argmax(1))
+    # class map must match the oracle wherever the oracle's top-2 margin exceeds the tolerance
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(pred.cpu().long()[safe], want.argmax(1)[safe])
+
+
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+@pytest.mark.parametrize('B', [3, 64, 300])
+def test_train_fwd_bwd_grads(name, B):
+    from dmf import lib
+    if name in ('hsi224', 'panms') and B == 300:
+        B = 260
+    cfg, ref, hip = nets(name)
+    a, b, t = rand_batch(name, B)
+    want_logits, want_loss, want_g = ref_grads(ref, a, b, t)
+    K = SHAPES[name][4]
+    ad, bd = a.cuda(), b.cuda()          # keep alive: the input descriptor holds raw device pointers
+    inp = lib.input_patches(hip.shape, ad, bd)
+    theta = hip.flat_parameters()
+    logits = torch.empty(B, K, device='cuda'); loss = torch.empty(B, device='cuda')
+    ws = hip.workspace(B)
+    lib.train_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t.int().cuda(), 1.0 / B, logits, loss, ws)
+    grad = torch.empty_like(theta)
+    lib.grad_reduce(hip.shape, B, ws, grad)
+    torch.cuda.synchronize()
+    assert_close(logits, want_logits, 1e-5, 0, 'train logits')
+    assert abs(loss.mean().item() - want_loss) < 1e-5
+    from model.gmfnet import PARAM_ORDER
+    off = hip._offsets
+    for i, k in enumerate(PARAM_ORDER):
+        g = grad[off[i]:off[i] + want_g[k].numel()].view(want_g[k].shape)
+        assert_close(g, want_g[k], 1e-5, 1e-4, 'grad %s [%s,B=%d]' % (k, name, B))
+
+
+@pytest.mark.parametrize('name', ['tiny', 'hsi'])
+def test_train_gather_equals_patches(name):
+    """Both input modes feed the same arithmetic: bit-identical logits, loss and gradient."""
+    from dmf import lib
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    H, W = 23, 19
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(3)
+    Bn = 130
+    xy = torch.stack([torch.randint(0, H, (Bn,), generator=g), torch.randint(0, W, (Bn,), generator=g)], 1).int()
+    t = torch.randint(0, K, (Bn,), generator=g).int().cuda()
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()]).contiguous().cuda()
+    b = torch.stack([Bm[S * x:S * x + S * P, S * y:S * y + S * P, :].permute(2, 0, 1) for x, y in xy.tolist()]).contiguous().cuda()
+    theta = hip.flat_parameters()
+    outs = []
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    for inp in (lib.input_patches(hip.shape, a, b), lib.input_gather(hip.shape, Ad, Bd, xyd)):
+        logits = torch.empty(Bn, K, device='cuda'); loss = torch.empty(Bn, device='cuda')
+        ws = torch.zeros(lib.workspace_bytes(hip.shape, Bn) // 4, device='cuda')
+        lib.train_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t, 1.0 / Bn, logits, loss, ws)
+        grad = torch.empty_like(theta)
+        lib.grad_reduce(hip.shape, Bn, ws, grad)
+        outs.append((logits.cpu(), loss.cpu(), grad.cpu()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('name', ['tiny', 'hsi'])
+def test_autograd_boundary(name):
+    """The reference solver's own step (mainsolver.py:51-55) through model.gmfnet.Net: torch CE + backward + Adam."""
+    cfg, ref, hip = nets(name)
+    B = 48
+    a, b, t = rand_batch(name, B)
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt_h = torch.optim.Adam(hip.parameters(), lr=1e-3)
+    ce = torch.nn.CrossEntropyLoss()
+    for step in range(3):
+        opt_r.zero_grad(); lr_ = ce(ref(a, b), t); lr_.backward(); opt_r.step()
+        opt_h.zero_grad(); lh = ce(hip(a.cuda(), b.cuda()), t.cuda()); lh.backward(); opt_h.step()
+        assert abs(lr_.item() - lh.item()) < 1e-5
+    sd_r, sd_h = ref.state_dict(), hip.state_dict()
+    assert list(sd_r.keys()) == list(sd_h.keys())
+    for k in sd_r:
+        assert_close(sd_h[k], sd_r[k], 2e-5, 1e-4, 'param %s after 3 Adam steps' % k)
+
+
+def test_fused_adam_matches_torch_adam():
+    """dmf_grad_reduce_adam == dmf_grad_reduce + torch.optim.Adam (utils/utils.py:10-12 defaults)."""
+    from dmf import lib
+    from oracle.gmfnet_ref import adam_step_ref
+    cfg, ref, hip = nets('tiny')
+    B = 64
+    a, b, t = rand_batch('tiny', B)
+    ad, bd = a.cuda(), b.cuda()
+    inp = lib.input_patches(hip.shape, ad, bd)
+    theta = hip.flat_parameters().clone()
+    K = SHAPES['tiny'][4]
+    m = torch.zeros_like(theta); v = torch.zeros_like(theta)
+    th_ref = theta.cpu().clone(); m_ref = torch.zeros_like(th_ref); v_ref = torch.zeros_like(th_ref)
+    logits = torch.empty(B, K, device='cuda'); loss = torch.empty(B, device='cuda')
+    ws = torch.empty(lib.workspace_bytes(hip.shape, B) // 4, device='cuda')
+    for step in range(1, 6):
+        lib.train_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t.int().cuda(), 1.0 / B, logits, loss, ws)
+        grad = torch.empty_like(theta)
+        lib.grad_reduce_adam(hip.shape, B, ws, theta, m, v, grad, 1e-3, 0.9, 0.999, 1e-8, step)
+        adam_step_ref(th_ref, grad.cpu(), m_ref, v_ref, step)
+        assert_close(theta, th_ref, 1e-7, 1e-6, 'theta after fused Adam step %d' % step)
+        th_ref = theta.cpu().clone(); m_ref = m.cpu().clone(); v_ref = v.cpu().clone()
+    # separate Adam entry point, with gradient scaling (the post-all-reduce 1/world_size)
+    th2 = theta.clone(); m2 = m.clone(); v2 = v.clone()
+    g = torch.randn_like(theta)
+    lib.adam_step(th2, g, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 6, 0.5)
+    th_c, m_c, v_c = theta.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+    adam_step_ref(th_c, g.cpu() * 0.5, m_c, v_c, 6)
+    assert_close(th2, th_c, 1e-7, 1e-6, 'dmf_adam_step')
+
+
+def test_confusion_labelmap_pan2ms(golden_dir):
+    from dmf import lib
+    from oracle import datapath_ref as d
+    g = torch.Generator().manual_seed(0)
+    K, B = 17, 5000
+    pred = torch.randint(0, K, (B,), generator=g).int(); tgt = torch.randint(0, K, (B,), generator=g).int()
+    mat = torch.zeros(K, K, dtype=torch.int64, device='cuda')
+    lib.confusion_accum(pred.cuda(), tgt.cuda(), K, mat)
+    lib.confusion_accum(pred.cuda()[:100], tgt.cuda()[:100], K, mat)
+    want = d.confusion(pred.numpy(), tgt.numpy(), K) + d.confusion(pred.numpy()[:100], tgt.numpy()[:100], K)
+    assert np.array_equal(mat.cpu().numpy().astype(np.float64), want)
+    H, W = 31, 17
+    xy = torch.stack([torch.arange(H * W) // W, torch.arange(H * W) % W], 1).int()
+    p2 = torch.randint(0, K, (H * W,), generator=g).int()
+    lm = torch.full((H, W), -1, dtype=torch.int32, device='cuda')
+    lib.labelmap_write(p2.cuda(), xy.cuda(), W, lm)
+    assert torch.equal(lm.cpu().reshape(-1), p2)
+    gg = np.load(os.path.join(golden_dir, 'g7_ihs.npz'))
+    for pan_key, out_key in (('pan', 'p2m'), ('pan_r', 'p2m_r')):
+        pan = torch.from_numpy(gg[pan_key]).cuda()
+        Ho, Wo = gg[out_key].shape[:2]
+        out = torch.empty(Ho, Wo, 4, dtype=torch.float64, device='cuda')
+        lib.pan2ms(pan, Ho, Wo, out)
+        assert np.array_equal(out.cpu().numpy(), gg[out_key]), 'pan2ms must be bit-exact (fp64, integer-like op)'
+
+
+def test_unsupported_shape_fails_loudly():
+    from dmf import lib
+    from model.gmfnet import Net
+    cfg = make_cfg('tiny'); cfg['patch_size'] = 7
+    net = Net(cfg).cuda()
+    with pytest.raises(lib.DmfError, match='no compiled kernel instance'):
+        net(torch.zeros(1, 8, 7, 7).cuda(), torch.zeros(1, 1, 28, 28).cuda())
+    with pytest.raises(lib.DmfError, match='GPU only'):
+        Net(make_cfg('tiny'))(torch.zeros(1, 8, 5, 5), torch.zeros(1, 1, 20, 20))
