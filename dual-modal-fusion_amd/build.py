@@ -22,11 +22,18 @@ def up_to_date():
     return all(os.path.getmtime(p) <= t for p in SRC + HDR + [os.path.abspath(__file__)])
 
 
-def build(force=False, verbose=True):
-    if not force and up_to_date():
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True builds the diagnostic variant libdmf_hip_stamps.so (-DDMF_STAMPS; tools/phase_profile.py)."""
+    if not stamps and not force and up_to_date():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + SRC + ['-o', OUT]
+    out = OUT.replace('.so', '_stamps.so') if stamps else OUT
+    cmd = [hipcc] + FLAGS + (['-DDMF_STAMPS'] if stamps else []) + SRC + ['-o', out]
+    if stamps:
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return out
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -35,3 +42,5 @@ def build(force=False, verbose=True):
 
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    if '--stamps' in sys.argv:
+        build(stamps=True)

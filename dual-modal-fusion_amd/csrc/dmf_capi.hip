@@ -27,10 +27,14 @@ struct KArgs {   // must match dmf_patch_kernel.hip
   float* ws_h;
   float* ws_dh;
   float* ws_dl;
+  int32_t* adam_step;
   int32_t K;
 };
 enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2 };
 
+#ifdef DMF_STAMPS
+hipError_t set_stamps(unsigned long long* p);
+#endif
 int patch_shape_supported(const dmf_shape& s);
 hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
 
@@ -61,7 +65,16 @@ struct ReduceArgs {
   float* grad;
   float* theta; float* m; float* v;   // Adam (theta == nullptr: reduce only)
   float lr, b1, b2, eps, bc1, bc2_sqrt;
+  const int32_t* step_dev;            // optional device-side step count (overrides bc1 / bc2_sqrt)
+  int32_t* cursor_dev;                // optional epoch-plan cursor to advance
+  const float* loss; float* loss_hist;
 };
+
+// bias corrections from a device-resident step count, in double like torch's host-side scalars
+__device__ __forceinline__ void bias_corrections(int step, float b1, float b2, float& bc1, float& bc2_sqrt) {
+  bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+}
 
 __device__ __forceinline__ void adam_update(float* theta, float* m, float* v, int64_t p, float g,
                                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
@@ -79,6 +92,15 @@ __device__ __forceinline__ void adam_update(float* theta, float* m, float* v, in
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
   __shared__ float part[8][32];
   const int jj = threadIdx.x & 31, ch = threadIdx.x >> 5;
+  if (blockIdx.x == 0 && threadIdx.x == 64) {        // bookkeeping lane: per-step mean loss, cursor advance
+    const int cur = a.cursor_dev != nullptr ? *a.cursor_dev : 0;
+    if (a.loss != nullptr && a.loss_hist != nullptr) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) s += a.loss[b];
+      a.loss_hist[cur] = s / (float)a.B;
+    }
+    if (a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
+  }
   const int64_t p = (int64_t)blockIdx.x * 32 + jj;
   float acc = 0.f;
   if (p < a.n) {
@@ -110,15 +132,21 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
     const float g = ((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj])) +
                     ((part[4][jj] + part[5][jj]) + (part[6][jj] + part[7][jj]));
     if (a.grad != nullptr) a.grad[p] = g;
-    if (a.theta != nullptr) adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, a.bc1, a.bc2_sqrt);
+    if (a.theta != nullptr) {
+      float bc1 = a.bc1, bc2s = a.bc2_sqrt;
+      if (a.step_dev != nullptr) bias_corrections(*a.step_dev, a.b1, a.b2, bc1, bc2s);
+      adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, bc1, bc2s);
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* theta, const float* grad, float* m, float* v, int64_t n,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                   float grad_scale) {
+                                                   float grad_scale, const int32_t* step_dev, int32_t* cursor_dev) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (step_dev != nullptr) bias_corrections(*step_dev, b1, b2, bc1, bc2_sqrt);
   if (p < n) adam_update(theta, m, v, p, grad[p] * grad_scale, lr, b1, b2, eps, bc1, bc2_sqrt);
+  if (cursor_dev != nullptr && p == 0) *cursor_dev += 1;
 }
 
 // ------------------------------------------------------------------------------ eval helpers
@@ -186,7 +214,7 @@ int64_t dmf_workspace_bytes(const dmf_shape* s, int32_t B) {
 
 static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const float* theta, const float* pool_w,
                      const int32_t* labels, const float* dlogits, float loss_scale, float* logits, float* loss,
-                     int32_t* pred, void* workspace, void* stream) {
+                     int32_t* pred, void* workspace, int32_t* adam_step, void* stream) {
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr) return fail("%s", "null argument");
   if (dmf_shape_supported(s)) return 1;
   if (in->B < 0) return fail("%s", "negative batch");
@@ -205,6 +233,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
   a.logits = logits;
   a.loss = loss;
   a.pred = pred;
+  a.adam_step = adam_step;
   a.K = s->K;
   if (mode != MODE_FWD) {
     if (workspace == nullptr) return fail("%s", "null workspace");
@@ -223,24 +252,25 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
 int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                     float* logits, int32_t* pred, void* stream) {
   if (logits == nullptr) return fail("%s", "null logits");
-  return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, stream);
+  return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, nullptr, stream);
 }
 
 int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                           const int32_t* labels, float loss_scale, float* logits, float* loss, void* workspace,
-                          void* stream) {
+                          int32_t* adam_step_dev, void* stream) {
   if (labels == nullptr || logits == nullptr || loss == nullptr) return fail("%s", "null labels/logits/loss");
-  return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, stream);
+  return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, adam_step_dev, stream);
 }
 
 int32_t dmf_backward_dlogits(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                              const float* dlogits, void* workspace, void* stream) {
   if (dlogits == nullptr) return fail("%s", "null dlogits");
-  return run_patch(s, in, MODE_BWD, theta, pool_w, nullptr, dlogits, 1.f, nullptr, nullptr, nullptr, workspace, stream);
+  return run_patch(s, in, MODE_BWD, theta, pool_w, nullptr, dlogits, 1.f, nullptr, nullptr, nullptr, workspace, nullptr, stream);
 }
 
 static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, float* theta, float* m,
-                      float* v, float lr, float b1, float b2, float eps, int32_t step, void* stream) {
+                      float* v, float lr, float b1, float b2, float eps, int32_t step, const int32_t* step_dev,
+                      int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream) {
   if (s == nullptr || workspace == nullptr) return fail("%s", "null argument");
   if (B <= 0) return fail("%s", "batch must be positive");
   const Layout L = layout_of(*s);
@@ -253,10 +283,13 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
   a.grad = grad; a.theta = theta; a.m = m; a.v = v;
   a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps;
   if (theta != nullptr) {
-    if (m == nullptr || v == nullptr || step < 1) return fail("%s", "Adam needs m, v and step >= 1");
-    a.bc1 = (float)(1.0 - pow((double)b1, (double)step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    if (m == nullptr || v == nullptr || (step < 1 && step_dev == nullptr)) return fail("%s", "Adam needs m, v and step >= 1");
+    if (step_dev == nullptr) {
+      a.bc1 = (float)(1.0 - pow((double)b1, (double)step));
+      a.bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+    }
   }
+  a.step_dev = step_dev; a.cursor_dev = cursor_dev; a.loss = loss; a.loss_hist = loss_hist;
   const int grid = (int)((L.n_params + 31) / 32);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check(hipGetLastError(), "grad_reduce launch");
@@ -264,23 +297,27 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
 
 int32_t dmf_grad_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, void* stream) {
   if (grad == nullptr) return fail("%s", "null grad");
-  return run_reduce(s, B, workspace, grad, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0, stream);
+  return run_reduce(s, B, workspace, grad, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int32_t dmf_grad_reduce_adam(const dmf_shape* s, int32_t B, const void* workspace, float* theta, float* m, float* v,
-                             float* grad, float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+                             float* grad, float lr, float beta1, float beta2, float eps, int32_t step,
+                             const int32_t* adam_step_dev, int32_t* cursor_dev, const float* loss, float* loss_hist,
+                             void* stream) {
   if (theta == nullptr) return fail("%s", "null theta");
-  return run_reduce(s, B, workspace, grad, theta, m, v, lr, beta1, beta2, eps, step, stream);
+  return run_reduce(s, B, workspace, grad, theta, m, v, lr, beta1, beta2, eps, step, adam_step_dev, cursor_dev, loss,
+                    loss_hist, stream);
 }
 
 int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
-                      float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+                      float beta2, float eps, int32_t step, float grad_scale, const int32_t* adam_step_dev,
+                      int32_t* cursor_dev, void* stream) {
   if (theta == nullptr || grad == nullptr || m == nullptr || v == nullptr) return fail("%s", "null argument");
-  if (n <= 0 || step < 1) return fail("%s", "n and step must be positive");
-  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  if (n <= 0 || (step < 1 && adam_step_dev == nullptr)) return fail("%s", "n and step must be positive");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)(step < 1 ? 1 : step)));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)(step < 1 ? 1 : step)));
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     theta, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+                     theta, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, adam_step_dev, cursor_dev);
   return check(hipGetLastError(), "adam launch");
 }
 
@@ -308,5 +345,9 @@ int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, doubl
                      pan, pitch, H, W, out);
   return check(hipGetLastError(), "pan2ms launch");
 }
+
+#ifdef DMF_STAMPS
+int32_t dmf_debug_set_stamps(void* p) { return check(dmf::set_stamps(static_cast<unsigned long long*>(p)), "set_stamps"); }
+#endif
 
 }  // extern "C"

@@ -5,21 +5,25 @@
 // `loss.backward()`  — solver/mainsolver.py:52-54 — and, in MODE_FWD, the eval forward + argmax
 // (mainsolver.py:109,139,169-170).  The arithmetic is the GMFNet stated in oracle/gmfnet_ref.py.
 //
-// Design (gfx950): one 512-thread workgroup (8 wave64) owns one patch at a time; the whole patch window
-// (P*P pixels x C bands, pixel-major) is staged once into LDS with 16-byte coalesced loads, every
-// activation stays in LDS/registers, and the only HBM writes are logits/loss, a handful of per-patch head
-// vectors and ONE gradient slab row per workgroup.  Reductions are fixed-order (no float atomics), so a
-// step is bitwise reproducible.
+// Design (gfx950): one workgroup (10 wave64 for F = 40) owns one patch at a time.  The patch window
+// (P*P pixels x C bands, pixel-major) is read from HBM/L2 ONCE with 16-byte coalesced loads issued back to
+// back, and stays in LDS until the last weight gradient has consumed it; every activation lives in LDS or
+// registers; per-thread weights (depthwise taps, fc rows) are loaded into registers once per workgroup.  The
+// only global writes are logits/loss, four small per-patch head vectors and ONE gradient slab row per
+// workgroup.  All reductions are fixed-order (shuffles / ordered LDS sums, no float atomics): a step is
+// bitwise reproducible.
 //
-//   P0  gather  X[pix][band]  (scene rows are P*C contiguous floats -> float4 loads), aux tile, pool profile
+//   P0  gather  X[pix][band]  (a scene row of the window is P*C contiguous floats), aux tile
 //   P1  spec_a  grouped 1x1:  wave-task = (group, 64-pixel half); lane <-> pixel, weights wave-uniform (SGPR)
-//       lift_b  SxS stride-S conv
-//   P2  spat_a / spat_b depthwise 3x3: thread <-> (channel,row), 3x3 window slides along the row in registers;
-//       ReLU masks kept as one 32-bit word per (channel,row); anchor-Gaussian pooling partials
-//   P3  head: fc1 / fc2 from LDS-staged weights, softmax-CE by wavefront shuffles, dlogits, dh, dz
-//   P4  backward of the depthwise stages from the row masks (dY2 = mask * dz[f] * pool[pix]),
-//       dW/db partials per row -> fixed-order row sum -> slab; dY1 rows overwrite Y1 in LDS
-//   P5  lift_b / bias gradients; X tile re-staged (2nd read, L2-resident) -> spec_a weight gradient
+//       lift_b  SxS stride-S conv: thread <-> (channel, 16 pixel lanes)
+//   P2  spat_a / spat_b depthwise 3x3: thread <-> (channel, row); the 3x3 window slides along the row in
+//       registers; ReLU masks kept as one word per (channel,row); anchor-Gaussian pooling reduced over the
+//       16 row lanes by shuffles
+//   P3  head: fc1 / fc2 from register-resident weight rows, softmax-CE by wavefront shuffles, dlogits;
+//       dh and dz re-use the same registers (transposed reduction by shuffles + one ordered LDS sum)
+//   P4  backward of the depthwise stages from the row masks (dY2 = mask * dz[f] * pool[pix]); dW/db reduced
+//       over rows by shuffles -> slab; dY1 rows overwrite Y1 in LDS
+//   P5  lift_b / bias gradients; spec_a weight gradient from the still-resident X tile
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -30,6 +34,18 @@
 namespace dmf {
 
 enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2 };
+
+// Diagnostic build only (-DDMF_STAMPS, tools/phase_profile.py): per-phase s_memtime stamps of wave 0, written to a
+// buffer nothing else reads.  The shipped library contains no stamp.
+#ifdef DMF_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define STAMP(i) do { if (threadIdx.x == 0 && g_stamps != nullptr) g_stamps[(size_t)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// Stops the compiler from hoisting per-thread address arithmetic out of the patch loop (it then spills it).
+#define OPAQUE(v) asm volatile("" : "+v"(v))
 
 struct KArgs {
   dmf_input in;
@@ -46,6 +62,7 @@ struct KArgs {
   float* ws_h;   // [B][H]
   float* ws_dh;  // [B][H]
   float* ws_dl;  // [B][KMAX]
+  int32_t* adam_step;   // device step counter to advance (nullable)
   int32_t K;
 };
 
@@ -59,10 +76,35 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
-__device__ __forceinline__ float sum8(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
+// Row reductions by DPP (VALU modifiers, no LDS crossbar round trip): xor-1 / xor-2 by quad_perm, then
+// row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) complete the butterfly inside 8 / 16 lanes.
+#define DMF_DPP_ADD(v, CTRL) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true)))
+__device__ __forceinline__ float sum8(float v) {          // over the 8 lanes sharing lane>>3
+  v = DMF_DPP_ADD(v, 0xB1);     // quad_perm [1,0,3,2]
+  v = DMF_DPP_ADD(v, 0x4E);     // quad_perm [2,3,0,1]
+  v = DMF_DPP_ADD(v, 0x141);    // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float sum16(float v) {         // over the 16 lanes sharing lane>>4
+  v = sum8(v);
+  v = DMF_DPP_ADD(v, 0x140);    // row_mirror
+  return v;
+}
+// over the 8 lanes sharing lane&7 (stride 8): xor-8 inside a row by row_ror:8, xor-16 / xor-32 by the gfx950
+// row / half swaps (v_permlane16_swap, v_permlane32_swap)
+__device__ __forceinline__ float sum_hi8(float v) {
+  v = DMF_DPP_ADD(v, 0x128);    // row_ror:8
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
   return v;
 }
 
@@ -73,73 +115,122 @@ struct Lds {
   static constexpr int Q = Sh::C / 4;                              // 16-byte band chunks per pixel
   static constexpr int UNITS = Q * (Sh::M / MB);
   static constexpr int NSL = (Sh::NT / UNITS) < 32 ? (Sh::NT / UNITS) : 32;  // pixel slices of the spec_a gradient
-  static constexpr int SCR = cmax(cmax(Sh::P2 * Sh::Cs, Sh::P * 2 * Sh::F * 10),
-                                  cmax(Sh::H * Sh::F2 + KMAX * Sh::H, NSL * Sh::F * Sh::Cg));
   static constexpr int AUXP = (Sh::PB * Sh::C2 + 3) & ~3;
   static constexpr int P2P = (Sh::P2 + 3) & ~3;
+  static constexpr int NWH = (Sh::H * 8 + 63) / 64;                // waves taking part in the head
+  static constexpr int WA = Sh::F * Sh::Cg + Sh::F;                // staged spec_a weight + bias
+  static constexpr int MS = Sh::P;                                 // row-mask stride per channel
+  static constexpr int REST = 2 * Sh::P2 * Sh::Fs + AUXP + P2P + 2 * Sh::F * MS + 2 * Sh::F2 + 2 * Sh::H + 2 * KMAX +
+                              NWH * cmax(Sh::F2, Sh::H) + ((WA + 3) & ~3);
+  // X-tile row stride (floats).  (Cs/4) odd makes a 16-lane ds_read_b128 group with lane<->pixel hit 64 distinct
+  // banks (MI355X_MICROARCH.md §LDS); the pad is dropped (2-way conflict) only where it would not fit in 160 KiB.
+  static constexpr int CsPad = Sh::C + ((((Sh::C / 4) & 1) == 0) ? 4 : 0);
+  static constexpr int Cs = (cmax(Sh::P2 * CsPad, NSL * Sh::F * Sh::Cg) + REST <= 40960) ? CsPad : Sh::C;
+  static constexpr int SCR = cmax(Sh::P2 * Cs, NSL * Sh::F * Sh::Cg);        // X tile, later its gradient partials
   // offsets in floats
-  static constexpr int oX = 0;                         // fwd: X tile; later: staged fc weights / scratch
-  static constexpr int oY1a = oX + SCR;
+  static constexpr int oX = 0;
+  static constexpr int oWa = oX + SCR;                             // [F][Cg] spec_a.weight, then [F] spec_a.bias
+  static constexpr int oY1a = oWa + ((WA + 3) & ~3);
   static constexpr int oY1b = oY1a + Sh::P2 * Sh::Fs;
   static constexpr int oAux = oY1b + Sh::P2 * Sh::Fs;
   static constexpr int oPool = oAux + AUXP;
   static constexpr int oMaskA = oPool + P2P;
-  static constexpr int oMaskB = oMaskA + Sh::F * Sh::P;
-  static constexpr int oZrow = oMaskB + Sh::F * Sh::P;  // [P][2F]   (also the dz partial scratch: needs P >= 4)
-  static constexpr int oZ = oZrow + Sh::P * Sh::F2;
+  static constexpr int oMaskB = oMaskA + Sh::F * MS;
+  static constexpr int oZ = oMaskB + Sh::F * MS;
   static constexpr int oH = oZ + Sh::F2;
   static constexpr int oDh = oH + Sh::H;
   static constexpr int oDz = oDh + Sh::H;
   static constexpr int oLg = oDz + Sh::F2;
   static constexpr int oDl = oLg + KMAX;
-  static constexpr int TOTAL = oDl + KMAX;
+  static constexpr int oTmp = oDl + KMAX;                          // [NWH][max(2F, H)] ordered partial sums
+  static constexpr int TOTAL = oTmp + NWH * cmax(Sh::F2, Sh::H);
   static constexpr int BYTES = TOTAL * 4;
+  static_assert(TOTAL == SCR + REST, "LDS carve");
   static_assert(BYTES <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
-  static_assert(Sh::P >= 4, "dz partial scratch reuses the [P][2F] row buffer");
 };
 
 // ---------------------------------------------------------------------------------------- P0 loaders
+// All loads of a thread are issued before the first LDS store, so the whole window is in flight at once.
 template <class Sh>
-__device__ __forceinline__ void load_x_tile(const dmf_input& in, int b, float* sX, int tid) {
+__device__ __forceinline__ void load_x_tile(const dmf_input& in, int b, float* __restrict__ sX, int tid) {
   if (in.mode == 1) {
-    const int x = in.xy[2 * b], y = in.xy[2 * b + 1];
+    const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
     constexpr int Q = Sh::C / 4;
     constexpr int NQ = Sh::P2 * Q;
+    constexpr int NIT = (NQ + Sh::NT - 1) / Sh::NT;
     const float4* __restrict__ src = reinterpret_cast<const float4*>(in.sceneA);
+    float4 v[NIT];
+    int dst[NIT];
 #pragma unroll
-    for (int q0 = 0; q0 < NQ; q0 += Sh::NT) {
-      const int q = q0 + tid;
-      if (q < NQ) {
-        const int pix = q / Q, cc = q - pix * Q;
-        const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
-        const size_t pixel = (size_t)(x + pr) * in.Wp + (y + pc);
-        const float4 v = src[pixel * Q + cc];
-        *reinterpret_cast<float4*>(sX + pix * Sh::Cs + 4 * cc) = v;
-      }
+    for (int i = 0; i < NIT; ++i) {
+      const int q = i * Sh::NT + tid;
+      const int qc = q < NQ ? q : NQ - 1;
+      const int pix = qc / Q, cc = qc - pix * Q;
+      const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
+      const size_t pixel = (size_t)(x + pr) * in.Wp + (y + pc);
+      v[i] = src[pixel * Q + cc];
+      dst[i] = q < NQ ? pix * Lds<Sh>::Cs + 4 * cc : -1;
     }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+      if (dst[i] >= 0) *reinterpret_cast<float4*>(sX + dst[i]) = v[i];
   } else {
     const float* __restrict__ src = in.a + (size_t)b * Sh::C * Sh::P2;
-    for (int e = tid; e < Sh::C * Sh::P2; e += Sh::NT) {
-      const int c = e / Sh::P2, pix = e - c * Sh::P2;
-      sX[pix * Sh::Cs + c] = src[e];
+    constexpr int NE = Sh::C * Sh::P2;
+    constexpr int UN = 8;
+    for (int e0 = 0; e0 < NE; e0 += UN * Sh::NT) {
+      float v[UN];
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int e = e0 + i * Sh::NT + tid;
+        v[i] = src[e < NE ? e : NE - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < UN; ++i) {
+        const int e = e0 + i * Sh::NT + tid;
+        if (e < NE) {
+          const int c = e / Sh::P2, pix = e - c * Sh::P2;
+          sX[pix * Lds<Sh>::Cs + c] = v[i];
+        }
+      }
     }
   }
 }
 
 template <class Sh>
-__device__ __forceinline__ void load_aux_tile(const dmf_input& in, int b, float* sAux, int tid) {
+__device__ __forceinline__ void load_aux_tile(const dmf_input& in, int b, float* __restrict__ sAux, int tid) {
   constexpr int ROW = Sh::SP * Sh::C2;
+  constexpr int NE = Sh::PB * Sh::C2;
+  constexpr int NIT = (NE + Sh::NT - 1) / Sh::NT;
+  float v[NIT];
   if (in.mode == 1) {
-    const int x = in.xy[2 * b], y = in.xy[2 * b + 1];
-    for (int e = tid; e < Sh::PB * Sh::C2; e += Sh::NT) {
-      const int r = e / ROW, rem = e - r * ROW;
-      sAux[e] = in.sceneB[((size_t)(Sh::S * x + r) * in.WpB + (size_t)Sh::S * y) * Sh::C2 + rem];
+    const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = i * Sh::NT + tid;
+      const int ec = e < NE ? e : NE - 1;
+      const int r = ec / ROW, rem = ec - r * ROW;
+      v[i] = in.sceneB[((size_t)(Sh::S * x + r) * in.WpB + (size_t)Sh::S * y) * Sh::C2 + rem];
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = i * Sh::NT + tid;
+      if (e < NE) sAux[e] = v[i];
     }
   } else {
     const float* __restrict__ src = in.b + (size_t)b * Sh::C2 * Sh::PB;
-    for (int e = tid; e < Sh::PB * Sh::C2; e += Sh::NT) {
-      const int k = e / Sh::PB, pixb = e - k * Sh::PB;
-      sAux[pixb * Sh::C2 + k] = src[e];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = i * Sh::NT + tid;
+      v[i] = src[e < NE ? e : NE - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int e = i * Sh::NT + tid;
+      if (e < NE) {
+        const int k = e / Sh::PB, pixb = e - k * Sh::PB;
+        sAux[pixb * Sh::C2 + k] = v[i];
+      }
     }
   }
 }
@@ -154,88 +245,171 @@ __device__ __forceinline__ void load_col(const float* sY1, int f, int r, int c, 
   }
 }
 
-// depthwise 3x3 (zero pad 1) + ReLU along one row; returns ReLU mask word and pooled partial sum
+// The row walkers slide the 3x3 windows of BOTH branches along one patch row in registers.  Column iteration c
+// first issues the LDS loads of column c+2, then computes column c from registers; the sched_barrier keeps the
+// compiler from hoisting every load of the unrolled row to its top (which spills), so the software pipeline is
+// two columns deep and the two branches give each other instruction-level parallelism.
 template <class Sh>
-__device__ __forceinline__ void row_conv_fwd(const float* sY1, const float* sPool, int f, int r,
-                                             const float w[9], float bias, uint32_t& mask, float& z) {
-  float c0[3] = {0.f, 0.f, 0.f}, c1[3], c2[3];
-  load_col<Sh>(sY1, f, r, 0, c1);
-  mask = 0u;
-  z = 0.f;
+__device__ __forceinline__ float conv9(const float w[9], const float l[3], const float m[3], const float r[3], float y) {
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    y = fmaf(w[u * 3 + 0], l[u], y);
+    y = fmaf(w[u * 3 + 1], m[u], y);
+    y = fmaf(w[u * 3 + 2], r[u], y);
+  }
+  return y;
+}
+
+// forward: depthwise 3x3 (zero pad 1) + ReLU of spat_a and spat_b on row r of channel f; ReLU mask words and
+// the pooled partial sums of the row
+template <class Sh>
+__device__ __forceinline__ void row_fwd2(const float* sYa, const float* sYb, const float* sPool, int f, int r,
+                                         const float wA[9], float bA, const float wB[9], float bB,
+                                         uint32_t& mkA, float& za, uint32_t& mkB, float& zb) {
+  float a0[3] = {0.f, 0.f, 0.f}, a1[3], a2[3] = {0.f, 0.f, 0.f}, an[3];
+  float b0[3] = {0.f, 0.f, 0.f}, b1[3], b2[3] = {0.f, 0.f, 0.f}, bn[3];
+  load_col<Sh>(sYa, f, r, 0, a1);
+  load_col<Sh>(sYb, f, r, 0, b1);
+  if (Sh::P > 1) { load_col<Sh>(sYa, f, r, 1, a2); load_col<Sh>(sYb, f, r, 1, b2); }
+  float pw = sPool[r * Sh::P], pn = 0.f;
+  mkA = mkB = 0u;
+  za = zb = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    if (c + 1 < Sh::P) load_col<Sh>(sY1, f, r, c + 1, c2);
-    else { c2[0] = c2[1] = c2[2] = 0.f; }
-    float y = bias;
+    if (c + 2 < Sh::P) { load_col<Sh>(sYa, f, r, c + 2, an); load_col<Sh>(sYb, f, r, c + 2, bn); }
+    else { an[0] = an[1] = an[2] = 0.f; bn[0] = bn[1] = bn[2] = 0.f; }
+    if (c + 1 < Sh::P) pn = sPool[r * Sh::P + c + 1];
+    const float ya = conv9<Sh>(wA, a0, a1, a2, bA);
+    const float yb = conv9<Sh>(wB, b0, b1, b2, bB);
+    if (ya > 0.f) { mkA |= (1u << c); za = fmaf(pw, ya, za); }
+    if (yb > 0.f) { mkB |= (1u << c); zb = fmaf(pw, yb, zb); }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      y = fmaf(w[u * 3 + 0], c0[u], y);
-      y = fmaf(w[u * 3 + 1], c1[u], y);
-      y = fmaf(w[u * 3 + 2], c2[u], y);
-    }
-    if (y > 0.f) {
-      mask |= (1u << c);
-      z = fmaf(sPool[r * Sh::P + c], y, z);
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) { c0[u] = c1[u]; c1[u] = c2[u]; }
+    for (int u = 0; u < 3; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; a2[u] = an[u]; b0[u] = b1[u]; b1[u] = b2[u]; b2[u] = bn[u]; }
+    pw = pn;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// backward of the same row: dW[9], db partial sums of this row and dY1 of this row.
-//   dY2(rr,cc) = mask(rr,cc) ? dzf * pool[rr,cc] : 0
-//   dW[u][v]  += dY2(r,c) * Y1(r+u-1, c+v-1)
-//   dY1(r,c)   = (Y1(r,c) > 0) * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1)
+// backward, pass 1 (before the barrier): weight / bias gradient partials of this row, both branches.
+//   dY2(r,c)  = mask(r,c) ? dz[f] * pool[r,c] : 0
+//   dW[u][v] += dY2(r,c) * Y1(r+u-1, c+v-1),  db += dY2(r,c)
 template <class Sh>
-__device__ __forceinline__ void row_conv_bwd(const float* sY1, const uint32_t* sMask, const float* sPool,
-                                             int f, int r, const float w[9], float dzf,
-                                             float dw[9], float& db, float dy1[Sh::P]) {
-  uint32_t mm[3];
+__device__ __forceinline__ void row_bwd_w2(const float* sYa, const float* sYb, const uint32_t* sMkA, const uint32_t* sMkB,
+                                           const float* sPool, int f, int r, float dza, float dzb,
+                                           float dwa[9], float& dba, float dwb[9], float& dbb) {
+  const uint32_t ma = sMkA[f * Lds<Sh>::MS + r], mb = sMkB[f * Lds<Sh>::MS + r];
+  float a0[3] = {0.f, 0.f, 0.f}, a1[3], a2[3] = {0.f, 0.f, 0.f}, an[3];
+  float b0[3] = {0.f, 0.f, 0.f}, b1[3], b2[3] = {0.f, 0.f, 0.f}, bn[3];
+  load_col<Sh>(sYa, f, r, 0, a1);
+  load_col<Sh>(sYb, f, r, 0, b1);
+  if (Sh::P > 1) { load_col<Sh>(sYa, f, r, 1, a2); load_col<Sh>(sYb, f, r, 1, b2); }
+  float pw = sPool[r * Sh::P], pn = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { dwa[k] = 0.f; dwb[k] = 0.f; }
+  dba = dbb = 0.f;
+#pragma unroll
+  for (int c = 0; c < Sh::P; ++c) {
+    if (c + 2 < Sh::P) { load_col<Sh>(sYa, f, r, c + 2, an); load_col<Sh>(sYb, f, r, c + 2, bn); }
+    else { an[0] = an[1] = an[2] = 0.f; bn[0] = bn[1] = bn[2] = 0.f; }
+    if (c + 1 < Sh::P) pn = sPool[r * Sh::P + c + 1];
+    const float da = ((ma >> c) & 1u) ? dza * pw : 0.f;
+    const float db = ((mb >> c) & 1u) ? dzb * pw : 0.f;
+    dba += da;
+    dbb += db;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      dwa[u * 3 + 0] = fmaf(da, a0[u], dwa[u * 3 + 0]);
+      dwa[u * 3 + 1] = fmaf(da, a1[u], dwa[u * 3 + 1]);
+      dwa[u * 3 + 2] = fmaf(da, a2[u], dwa[u * 3 + 2]);
+      dwb[u * 3 + 0] = fmaf(db, b0[u], dwb[u * 3 + 0]);
+      dwb[u * 3 + 1] = fmaf(db, b1[u], dwb[u * 3 + 1]);
+      dwb[u * 3 + 2] = fmaf(db, b2[u], dwb[u * 3 + 2]);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; a2[u] = an[u]; b0[u] = b1[u]; b1[u] = b2[u]; b2[u] = bn[u]; }
+    pw = pn;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// backward, pass 2 (after the barrier: no thread reads a neighbour's Y1 any more): dY1 of this row, in place, for
+// both branches, plus this row's share of the bias gradients of spec_a / lift_b and of the lift_b weight gradient.
+//   dY1(r,c) = (Y1(r,c) > 0) * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1)
+//   d lift_b.weight[f][k][u][v] += dY1b(r,c) * aux[k][S r + u][S c + v]
+template <class Sh>
+__device__ __forceinline__ void row_bwd_x2(float* sYa, float* sYb, const uint32_t* sMkA, const uint32_t* sMkB,
+                                           const float* sPool, const float* sAux, int f, int r,
+                                           const float wA[9], const float wB[9], float dza, float dzb,
+                                           float& dbias_a, float& dbias_b, float dwl[Sh::TB]) {
+  uint32_t ma[3], mb[3];
+  int rc[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int rr = r + u - 1;
-    mm[u] = (rr >= 0 && rr < Sh::P) ? sMask[rr * Sh::F + f] : 0u;
+    const bool in = rr >= 0 && rr < Sh::P;
+    ma[u] = in ? sMkA[f * Lds<Sh>::MS + rr] : 0u;     // the masks are 0 outside the patch
+    mb[u] = in ? sMkB[f * Lds<Sh>::MS + rr] : 0u;
+    rc[u] = in ? rr : r;
   }
-  auto gval = [&](int u, int c) -> float {   // dY2 at (r+u-1, c)
-    const int rr = r + u - 1;
-    return ((mm[u] >> c) & 1u) ? dzf * sPool[rr * Sh::P + c] : 0.f;
-  };
-  float y0[3] = {0.f, 0.f, 0.f}, y1[3], y2[3];
-  float g0[3] = {0.f, 0.f, 0.f}, g1[3], g2[3];
-  load_col<Sh>(sY1, f, r, 0, y1);
+  // g*[col][u] = dY2 at (r+u-1, col); three columns live: c-1, c, c+1
+  float ga0[3] = {0.f, 0.f, 0.f}, ga1[3], ga2[3], gb0[3] = {0.f, 0.f, 0.f}, gb1[3], gb2[3];
+  float pn[3];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) g1[u] = gval(u, 0);
+  for (int u = 0; u < 3; ++u) {
+    const float pw = sPool[rc[u] * Sh::P];
+    ga1[u] = (ma[u] & 1u) ? dza * pw : 0.f;
+    gb1[u] = (mb[u] & 1u) ? dzb * pw : 0.f;
+    pn[u] = (Sh::P > 1) ? sPool[rc[u] * Sh::P + 1] : 0.f;
+  }
+  float ya = sYa[(r * Sh::P) * Sh::Fs + f], yb = sYb[(r * Sh::P) * Sh::Fs + f];
+  dbias_a = dbias_b = 0.f;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) dw[k] = 0.f;
-  db = 0.f;
+  for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    if (c + 1 < Sh::P) {
-      load_col<Sh>(sY1, f, r, c + 1, y2);
-#pragma unroll
-      for (int u = 0; u < 3; ++u) g2[u] = gval(u, c + 1);
-    } else {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) { y2[u] = 0.f; g2[u] = 0.f; }
-    }
-    const float d2 = g1[1];
-    db += d2;
+    // column c+1 of dY2 from the pool values fetched one iteration ago; fetch column c+2's pool and column c+1's Y1
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      dw[u * 3 + 0] = fmaf(d2, y0[u], dw[u * 3 + 0]);
-      dw[u * 3 + 1] = fmaf(d2, y1[u], dw[u * 3 + 1]);
-      dw[u * 3 + 2] = fmaf(d2, y2[u], dw[u * 3 + 2]);
+      ga2[u] = (c + 1 < Sh::P && ((ma[u] >> (c + 1)) & 1u)) ? dza * pn[u] : 0.f;
+      gb2[u] = (c + 1 < Sh::P && ((mb[u] >> (c + 1)) & 1u)) ? dzb * pn[u] : 0.f;
     }
-    float s = 0.f;
+    if (c + 2 < Sh::P) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) pn[u] = sPool[rc[u] * Sh::P + c + 2];
+    }
+    float yan = 0.f, ybn = 0.f;
+    if (c + 1 < Sh::P) { yan = sYa[(r * Sh::P + c + 1) * Sh::Fs + f]; ybn = sYb[(r * Sh::P + c + 1) * Sh::Fs + f]; }
+    float ax[Sh::TB];
+#pragma unroll
+    for (int k = 0; k < Sh::C2; ++k)
+#pragma unroll
+      for (int u = 0; u < Sh::S; ++u)
+#pragma unroll
+        for (int v = 0; v < Sh::S; ++v)
+          ax[(k * Sh::S + u) * Sh::S + v] = sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k];
+    float sa = 0.f, sb = 0.f;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {   // W[u][v] pairs with dY2(r-u+1, c-v+1) = G[2-u][2-v]
-      s = fmaf(w[u * 3 + 0], g2[2 - u], s);
-      s = fmaf(w[u * 3 + 1], g1[2 - u], s);
-      s = fmaf(w[u * 3 + 2], g0[2 - u], s);
+      sa = fmaf(wA[u * 3 + 0], ga2[2 - u], sa);
+      sa = fmaf(wA[u * 3 + 1], ga1[2 - u], sa);
+      sa = fmaf(wA[u * 3 + 2], ga0[2 - u], sa);
+      sb = fmaf(wB[u * 3 + 0], gb2[2 - u], sb);
+      sb = fmaf(wB[u * 3 + 1], gb1[2 - u], sb);
+      sb = fmaf(wB[u * 3 + 2], gb0[2 - u], sb);
     }
-    dy1[c] = (y1[1] > 0.f) ? s : 0.f;
+    const float da = (ya > 0.f) ? sa : 0.f;
+    const float db = (yb > 0.f) ? sb : 0.f;
+    sYa[(r * Sh::P + c) * Sh::Fs + f] = da;
+    sYb[(r * Sh::P + c) * Sh::Fs + f] = db;
+    dbias_a += da;
+    dbias_b += db;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { y0[u] = y1[u]; y1[u] = y2[u]; g0[u] = g1[u]; g1[u] = g2[u]; }
+    for (int q = 0; q < Sh::TB; ++q) dwl[q] = fmaf(db, ax[q], dwl[q]);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { ga0[u] = ga1[u]; ga1[u] = ga2[u]; gb0[u] = gb1[u]; gb1[u] = gb2[u]; }
+    ya = yan;
+    yb = ybn;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -245,40 +419,83 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   using L = Lds<Sh>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem + L::oX;
+  float* sWa = smem + L::oWa;
   float* sY1a = smem + L::oY1a;
   float* sY1b = smem + L::oY1b;
   float* sAux = smem + L::oAux;
   float* sPool = smem + L::oPool;
-  uint32_t* sMaskA = reinterpret_cast<uint32_t*>(smem + L::oMaskA);
+  uint32_t* sMaskA = reinterpret_cast<uint32_t*>(smem + L::oMaskA);   // [F][16] row masks of spat_a's ReLU
   uint32_t* sMaskB = reinterpret_cast<uint32_t*>(smem + L::oMaskB);
-  float* sZrow = smem + L::oZrow;
   float* sZ = smem + L::oZ;
   float* sH = smem + L::oH;
   float* sDh = smem + L::oDh;
   float* sDz = smem + L::oDz;
   float* sLg = smem + L::oLg;
   float* sDl = smem + L::oDl;
-  float* sW1 = sX;                       // staged fc1.weight [H][2F]   (valid P2..P3)
-  float* sW2 = sX + Sh::H * Sh::F2;      // staged fc2.weight [K][H]
+  float* sTmp = smem + L::oTmp;
+  constexpr int TMPW = L::cmax(Sh::F2, Sh::H);
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const float* __restrict__ th = a.theta;
   const int K = a.K;
   const int B = a.in.B;
   float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB;
 
-  for (int i = tid; i < Sh::P2; i += Sh::NT) sPool[i] = a.pool[i];
+  for (int i = tid0; i < Sh::P2; i += Sh::NT) sPool[i] = a.pool[i];
+  // spec_a weights + bias -> LDS once per workgroup (read back as wave-uniform broadcasts in P1; the compiler
+  // cannot prove theta read-only, so it would otherwise fetch them through per-lane vector loads)
+  for (int i = tid0; i < L::WA; i += Sh::NT) sWa[i] = th[Sh::oA1w + i];
+  if (MODE == MODE_TRAIN && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
+  const int boff = (a.in.cursor != nullptr) ? a.in.cursor[0] * B : 0;   // epoch-plan offset of this batch
+
+  constexpr int N1 = (Sh::F2 + 7) / 8, N2 = (Sh::H + 7) / 8;
+  constexpr int NPL = Sh::NT / Sh::F;
 
   bool first = true;
   for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
+    int tid = tid0;
+    OPAQUE(tid);    // roles are re-derived from an opaque copy per patch (and again per backward phase) so their
+                    // address arithmetic lives inside the phase that uses it
+    // spatial stages: thread <-> (channel fS, row rS);  head: thread <-> (row jH of fc1 / fc2, part pH), column
+    // i = pH + 8*m;  lift_b: thread <-> (channel fL, pixel lane pL)
+    int fS = tid >> 4, rS = tid & 15;
+    const bool spat = fS < Sh::F;
+    const int fSc = spat ? fS : Sh::F - 1;
+    const int jH = tid >> 3, pH = tid & 7;
+    const int fL = tid % Sh::F, pL = tid / Sh::F;
     // ------------------------------------------------------------------ P0
-    load_x_tile<Sh>(a.in, b, sX, tid);
-    load_aux_tile<Sh>(a.in, b, sAux, tid);
+    STAMP(0);
+    load_x_tile<Sh>(a.in, boff + b, sX, tid);
+    load_aux_tile<Sh>(a.in, boff + b, sAux, tid);
     __syncthreads();
+    STAMP(1);
 
-    // ------------------------------------------------------------------ P1: spec_a (grouped 1x1) + ReLU
+    // per-thread weights for this patch: issued here, first used in P2 / P3, so their L2 latency hides under P1
+    float wA[9], wB[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wA[k] = th[Sh::oA2w + fSc * 9 + k]; wB[k] = th[Sh::oB2w + fSc * 9 + k]; }
+    const float bA = th[Sh::oA2b + fSc], bB = th[Sh::oB2b + fSc];
+    float w1r[N1], w2r[N2];
+#pragma unroll
+    for (int m = 0; m < N1; ++m) {
+      const int i = pH + 8 * m;
+      w1r[m] = (jH < Sh::H && i < Sh::F2) ? th[Sh::oFc1w + jH * Sh::F2 + i] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < N2; ++m) {
+      const int j = pH + 8 * m;
+      w2r[m] = (jH < K && j < Sh::H) ? th[Sh::oFc2w + jH * Sh::H + j] : 0.f;
+    }
+    const float b1H = (jH < Sh::H) ? th[Sh::oFc1b + jH] : 0.f;
+    const float b2H = (jH < K) ? th[Sh::oFc2w + K * Sh::H + jH] : 0.f;
+    float wL[Sh::TB];
+#pragma unroll
+    for (int q = 0; q < Sh::TB; ++q) wL[q] = th[Sh::oB1w + fL * Sh::TB + q];
+    const float bL = th[Sh::oB1b + fL];
+
+    // ------------------------------------------------------------------ P1: spec_a (grouped 1x1) + ReLU, lift_b
     {
       constexpr int NPH = (Sh::P2 + 63) / 64;
       for (int task = wave; task < Sh::G * NPH; task += Sh::NW) {
@@ -286,11 +503,11 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         const int pix = ph * 64 + lane;
         const bool valid = pix < Sh::P2;
         const int pixc = valid ? pix : Sh::P2 - 1;
-        const float* __restrict__ wg = th + Sh::oA1w + g * Sh::M * Sh::Cg;
+        const float* wg = sWa + g * Sh::M * Sh::Cg;
         float acc[Sh::M];
 #pragma unroll
-        for (int m = 0; m < Sh::M; ++m) acc[m] = th[Sh::oA1b + g * Sh::M + m];
-        const float* xr = sX + pixc * Sh::Cs + g * Sh::Cg;
+        for (int m = 0; m < Sh::M; ++m) acc[m] = sWa[Sh::F * Sh::Cg + g * Sh::M + m];
+        const float* xr = sX + pixc * Lds<Sh>::Cs + g * Sh::Cg;
 #pragma unroll
         for (int j4 = 0; j4 < Sh::Cg / 4; ++j4) {
           const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * j4);
@@ -308,68 +525,62 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         }
       }
       // lift_b (SxS stride-S conv) + ReLU
-      for (int e = tid; e < Sh::P2 * Sh::F; e += Sh::NT) {
-        const int pix = e / Sh::F, f = e - pix * Sh::F;
-        const int r = pix / Sh::P, c = pix - r * Sh::P;
-        float acc = th[Sh::oB1b + f];
+      if (pL < NPL) {
+        for (int pix = pL; pix < Sh::P2; pix += NPL) {
+          const int r = pix / Sh::P, c = pix - r * Sh::P;
+          float acc = bL;
 #pragma unroll
-        for (int k = 0; k < Sh::C2; ++k)
+          for (int k = 0; k < Sh::C2; ++k)
 #pragma unroll
-          for (int u = 0; u < Sh::S; ++u)
+            for (int u = 0; u < Sh::S; ++u)
 #pragma unroll
-            for (int v = 0; v < Sh::S; ++v)
-              acc = fmaf(th[Sh::oB1w + f * Sh::TB + (k * Sh::S + u) * Sh::S + v],
-                         sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k], acc);
-        sY1b[pix * Sh::Fs + f] = fmaxf(acc, 0.f);
+              for (int v = 0; v < Sh::S; ++v)
+                acc = fmaf(wL[(k * Sh::S + u) * Sh::S + v],
+                           sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k], acc);
+          sY1b[pix * Sh::Fs + fL] = fmaxf(acc, 0.f);
+        }
       }
     }
     __syncthreads();
+    STAMP(2);
 
     // ------------------------------------------------------------------ P2: depthwise 3x3 + ReLU + pooling
-    for (int i = tid; i < Sh::H * Sh::F2; i += Sh::NT) sW1[i] = th[Sh::oFc1w + i];
-    for (int i = tid; i < K * Sh::H; i += Sh::NT) sW2[i] = th[Sh::oFc2w + i];
-    if (tid < Sh::F * Sh::P) {
-      const int f = tid % Sh::F, r = tid / Sh::F;
-      float w[9];
-      uint32_t mk;
-      float z;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) w[k] = th[Sh::oA2w + f * 9 + k];
-      row_conv_fwd<Sh>(sY1a, sPool, f, r, w, th[Sh::oA2b + f], mk, z);
-      sMaskA[r * Sh::F + f] = mk;
-      sZrow[r * Sh::F2 + f] = z;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) w[k] = th[Sh::oB2w + f * 9 + k];
-      row_conv_fwd<Sh>(sY1b, sPool, f, r, w, th[Sh::oB2b + f], mk, z);
-      sMaskB[r * Sh::F + f] = mk;
-      sZrow[r * Sh::F2 + Sh::F + f] = z;
+    {
+      float za = 0.f, zb = 0.f;
+      if (spat && rS < Sh::P) {
+        uint32_t mka, mkb;
+        row_fwd2<Sh>(sY1a, sY1b, sPool, fS, rS, wA, bA, wB, bB, mka, za, mkb, zb);
+        sMaskA[fS * L::MS + rS] = mka;
+        sMaskB[fS * L::MS + rS] = mkb;
+      }
+      za = sum16(za);
+      zb = sum16(zb);
+      if (spat && rS == 0) { sZ[fS] = za; sZ[Sh::F + fS] = zb; }
     }
     __syncthreads();
+    STAMP(3);
 
     // ------------------------------------------------------------------ P3: head
-    if (tid < Sh::F2) {
-      float s = 0.f;
+    {
+      float acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < Sh::P; ++r) s += sZrow[r * Sh::F2 + tid];
-      sZ[tid] = s;
+      for (int m = 0; m < N1; ++m) {
+        const int i = pH + 8 * m;
+        acc = fmaf(w1r[m], (i < Sh::F2) ? sZ[i] : 0.f, acc);
+      }
+      acc = sum8(acc);
+      if (jH < Sh::H && pH == 0) sH[jH] = fmaxf(acc + b1H, 0.f);
     }
     __syncthreads();
     {
-      const int j = tid >> 3, part = tid & 7;
       float acc = 0.f;
-      if (j < Sh::H)
-        for (int i = part; i < Sh::F2; i += 8) acc = fmaf(sW1[j * Sh::F2 + i], sZ[i], acc);
+#pragma unroll
+      for (int m = 0; m < N2; ++m) {
+        const int j = pH + 8 * m;
+        acc = fmaf(w2r[m], (j < Sh::H) ? sH[j] : 0.f, acc);
+      }
       acc = sum8(acc);
-      if (j < Sh::H && part == 0) sH[j] = fmaxf(acc + th[Sh::oFc1b + j], 0.f);
-    }
-    __syncthreads();
-    {
-      const int k = tid >> 3, part = tid & 7;
-      float acc = 0.f;
-      if (k < K)
-        for (int j = part; j < Sh::H; j += 8) acc = fmaf(sW2[k * Sh::H + j], sH[j], acc);
-      acc = sum8(acc);
-      if (k < K && part == 0) sLg[k] = acc + th[Sh::oFc2w + K * Sh::H + k];
+      if (jH < K && pH == 0) sLg[jH] = acc + b2H;
     }
     __syncthreads();
     if (wave == 0) {   // softmax cross-entropy by wavefront shuffles (one wave64 covers K <= 64 logits)
@@ -385,7 +596,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       if (MODE == MODE_TRAIN) {
         const float e = lane < K ? expf(v - mx) : 0.f;
         const float s = wave_sum(e);
-        int t = a.labels[b];
+        int t = a.labels[boff + b];
         t = t < 0 ? 0 : (t >= K ? K - 1 : t);
         if (lane < K) sDl[lane] = (e / s - (lane == t ? 1.f : 0.f)) * a.loss_scale;
         if (lane == 0) a.loss[b] = (mx + logf(s)) - sLg[t];
@@ -395,19 +606,35 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     }
     if (MODE == MODE_FWD) {
       __syncthreads();
+      STAMP(4);
       continue;
     }
     __syncthreads();
+    STAMP(4);
 
-    // head backward: dh, then dz (4 partial sums through LDS, fixed order)
+    // head backward with the register-resident rows:
+    //   dh[j] = relu'(h[j]) * sum_k W2[k][j] dl[k]   : thread (k, part) holds W2[k][part + 8m]
+    //   dz[i] =               sum_j W1[j][i] dh[j]   : thread (j, part) holds W1[j][part + 8m]
+    // sum over the 8 rows of a wave by shuffles (lane stride 8), then over waves in fixed order through LDS.
+    {
+      const float dl = (jH < K) ? sDl[jH] : 0.f;
+#pragma unroll
+      for (int m = 0; m < N2; ++m) {
+        const float p = sum_hi8(w2r[m] * dl);
+        const int j = pH + 8 * m;
+        if (wave < L::NWH && (lane >> 3) == 0 && j < Sh::H) sTmp[wave * TMPW + j] = p;
+      }
+    }
+    __syncthreads();
     if (tid < Sh::H) {
-      float acc = 0.f;
+      float s = 0.f;
+      const int nwk = (K * 8 + 63) / 64;      // waves that hold rows of fc2
+      for (int w = 0; w < nwk; ++w) s += sTmp[w * TMPW + tid];
       const float hv = sH[tid];
-      if (hv > 0.f)
-        for (int k = 0; k < K; ++k) acc = fmaf(sW2[k * Sh::H + tid], sDl[k], acc);
-      sDh[tid] = acc;
+      const float dh = hv > 0.f ? s : 0.f;
+      sDh[tid] = dh;
       a.ws_h[(size_t)b * Sh::H + tid] = hv;
-      a.ws_dh[(size_t)b * Sh::H + tid] = acc;
+      a.ws_dh[(size_t)b * Sh::H + tid] = dh;
     } else if (tid >= 64 && tid < 64 + KMAX) {
       const int k = tid - 64;
       a.ws_dl[(size_t)b * KMAX + k] = k < K ? sDl[k] : 0.f;
@@ -415,85 +642,84 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       a.ws_z[(size_t)b * Sh::F2 + (tid - 128)] = sZ[tid - 128];
     }
     __syncthreads();
-    if (tid < 4 * Sh::F2) {
-      const int part = tid / Sh::F2, i = tid - part * Sh::F2;
-      float acc = 0.f;
-      for (int j = part; j < Sh::H; j += 4) acc = fmaf(sW1[j * Sh::F2 + i], sDh[j], acc);
-      sZrow[part * Sh::F2 + i] = acc;
-    }
-    __syncthreads();
-    if (tid < Sh::F2)
-      sDz[tid] = (sZrow[tid] + sZrow[Sh::F2 + tid]) + (sZrow[2 * Sh::F2 + tid] + sZrow[3 * Sh::F2 + tid]);
-    __syncthreads();
-
-    // ------------------------------------------------------------------ P4: depthwise backward
-    float dy1a[Sh::P], dy1b[Sh::P];
-    float* sScr = sX;   // [P][2][F][10] row partials of (dW[9], db)
-    if (tid < Sh::F * Sh::P) {
-      const int f = tid % Sh::F, r = tid / Sh::F;
-      float w[9], dw[9], db;
+    {
+      const float dh = (jH < Sh::H) ? sDh[jH] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) w[k] = th[Sh::oA2w + f * 9 + k];
-      row_conv_bwd<Sh>(sY1a, sMaskA, sPool, f, r, w, sDz[f], dw, db, dy1a);
-      float* dst = sScr + ((r * 2 + 0) * Sh::F + f) * 10;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) dst[k] = dw[k];
-      dst[9] = db;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) w[k] = th[Sh::oB2w + f * 9 + k];
-      row_conv_bwd<Sh>(sY1b, sMaskB, sPool, f, r, w, sDz[Sh::F + f], dw, db, dy1b);
-      dst = sScr + ((r * 2 + 1) * Sh::F + f) * 10;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) dst[k] = dw[k];
-      dst[9] = db;
-    }
-    __syncthreads();
-    if (tid < Sh::F * Sh::P) {   // dY1 rows overwrite Y1 (all window reads of Y1 are done)
-      const int f = tid % Sh::F, r = tid / Sh::F;
-#pragma unroll
-      for (int c = 0; c < Sh::P; ++c) {
-        sY1a[(r * Sh::P + c) * Sh::Fs + f] = dy1a[c];
-        sY1b[(r * Sh::P + c) * Sh::Fs + f] = dy1b[c];
+      for (int m = 0; m < N1; ++m) {
+        const float p = sum_hi8(w1r[m] * dh);
+        const int i = pH + 8 * m;
+        if (wave < L::NWH && (lane >> 3) == 0 && i < Sh::F2) sTmp[wave * TMPW + i] = p;
       }
     }
-    for (int e = tid; e < 2 * Sh::F * 10; e += Sh::NT) {
-      const int br = e / (Sh::F * 10), rem = e - br * (Sh::F * 10);
-      const int f = rem / 10, j = rem - f * 10;
+    __syncthreads();
+    if (tid < Sh::F2) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < Sh::P; ++r) s += sScr[((r * 2 + br) * Sh::F + f) * 10 + j];
-      const int off = (j < 9) ? ((br ? Sh::oB2w : Sh::oA2w) + f * 9 + j) : ((br ? Sh::oB2b : Sh::oA2b) + f);
-      slab[off] = first ? s : slab[off] + s;
+      for (int w = 0; w < L::NWH; ++w) s += sTmp[w * TMPW + tid];
+      sDz[tid] = s;
     }
     __syncthreads();
+    STAMP(5);
 
-    // ------------------------------------------------------------------ P5: lift_b / bias grads, spec_a weight grad
-    load_x_tile<Sh>(a.in, b, sX, tid);   // 2nd read of the window (the fwd copy was recycled as scratch)
+    // ------------------------------------------------------------------ P4: depthwise backward
+    OPAQUE(tid);
+    fS = tid >> 4; rS = tid & 15;
     {
-      constexpr int NQ = Sh::TB + 2;     // q < TB: lift tap, q == TB: lift bias, q == TB+1: spec_a bias
-      for (int e = tid; e < Sh::F * NQ * 8; e += Sh::NT) {
-        const int sl = e & 7, fq = e >> 3;
-        const int f = fq / NQ, q = fq - f * NQ;
-        float acc = 0.f;
-        if (q < Sh::TB) {
-          const int k = q / (Sh::S * Sh::S), uv = q - k * (Sh::S * Sh::S);
-          const int u = uv / Sh::S, v = uv - u * Sh::S;
-          for (int pix = sl; pix < Sh::P2; pix += 8) {
-            const int r = pix / Sh::P, c = pix - r * Sh::P;
-            acc = fmaf(sY1b[pix * Sh::Fs + f], sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k], acc);
-          }
-        } else {
-          const float* sY = (q == Sh::TB) ? sY1b : sY1a;
-          for (int pix = sl; pix < Sh::P2; pix += 8) acc += sY[pix * Sh::Fs + f];
+      const bool act = spat && rS < Sh::P;
+      float dwa[9], dwb[9], dba = 0.f, dbb = 0.f;
+      if (act) {
+        row_bwd_w2<Sh>(sY1a, sY1b, sMaskA, sMaskB, sPool, fS, rS, sDz[fS], sDz[Sh::F + fS], dwa, dba, dwb, dbb);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { dwa[k] = 0.f; dwb[k] = 0.f; }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { dwa[k] = sum16(dwa[k]); dwb[k] = sum16(dwb[k]); }
+      dba = sum16(dba);
+      dbb = sum16(dbb);
+      if (spat && rS == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int oa = Sh::oA2w + fS * 9 + k, ob = Sh::oB2w + fS * 9 + k;
+          slab[oa] = first ? dwa[k] : slab[oa] + dwa[k];
+          slab[ob] = first ? dwb[k] : slab[ob] + dwb[k];
         }
-        acc = sum8(acc);
-        if (sl == 0) {
-          const int off = (q < Sh::TB) ? (Sh::oB1w + f * Sh::TB + q) : (q == Sh::TB ? Sh::oB1b + f : Sh::oA1b + f);
-          slab[off] = first ? acc : slab[off] + acc;
+        slab[Sh::oA2b + fS] = first ? dba : slab[Sh::oA2b + fS] + dba;
+        slab[Sh::oB2b + fS] = first ? dbb : slab[Sh::oB2b + fS] + dbb;
+      }
+    }
+    __syncthreads();
+    STAMP(6);
+    OPAQUE(tid);
+    fS = tid >> 4; rS = tid & 15;
+    {   // dY1 rows overwrite Y1 in place (all window reads of Y1 are done); spec_a / lift_b bias and lift_b weight grads
+      float ga = 0.f, gb = 0.f, dwl[Sh::TB];
+      if (spat && rS < Sh::P) {
+        row_bwd_x2<Sh>(sY1a, sY1b, sMaskA, sMaskB, sPool, sAux, fS, rS, wA, wB, sDz[fS], sDz[Sh::F + fS], ga, gb, dwl);
+      } else {
+#pragma unroll
+        for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
+      }
+      ga = sum16(ga);
+      gb = sum16(gb);
+#pragma unroll
+      for (int q = 0; q < Sh::TB; ++q) dwl[q] = sum16(dwl[q]);
+      if (spat && rS == 0) {
+        slab[Sh::oA1b + fS] = first ? ga : slab[Sh::oA1b + fS] + ga;
+        slab[Sh::oB1b + fS] = first ? gb : slab[Sh::oB1b + fS] + gb;
+#pragma unroll
+        for (int q = 0; q < Sh::TB; ++q) {
+          const int o = Sh::oB1w + fS * Sh::TB + q;
+          slab[o] = first ? dwl[q] : slab[o] + dwl[q];
         }
       }
     }
     __syncthreads();
+    STAMP(7);
+
+    // ------------------------------------------------------------------ P5: spec_a weight grad from the resident X tile
+    OPAQUE(tid);
+    STAMP(8);
     {
       constexpr int Q = L::Q, MB = L::MB, UNITS = L::UNITS, NSL = L::NSL;
       const int u = tid % UNITS, sl = tid / UNITS;
@@ -504,7 +730,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       for (int m = 0; m < MB; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.f;
       if (sl < NSL) {
         for (int pix = sl; pix < Sh::P2; pix += NSL) {
-          const float4 xv = *reinterpret_cast<const float4*>(sX + pix * Sh::Cs + 4 * cc);
+          const float4 xv = *reinterpret_cast<const float4*>(sX + pix * Lds<Sh>::Cs + 4 * cc);
           const float* dy = sY1a + pix * Sh::Fs + g * Sh::M + mb * MB;
 #pragma unroll
           for (int m = 0; m < MB; ++m) {
@@ -517,12 +743,13 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         }
       }
       __syncthreads();   // X tile is dead: recycle it as [NSL][F*Cg] partials
+      STAMP(9);
       if (sl < NSL) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
           const int fo = g * Sh::M + mb * MB + m;
           float* dst = sX + sl * (Sh::F * Sh::Cg) + fo * Sh::Cg + (4 * cc - g * Sh::Cg);
-          dst[0] = acc[m][0]; dst[1] = acc[m][1]; dst[2] = acc[m][2]; dst[3] = acc[m][3];
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         }
       }
       __syncthreads();
@@ -534,6 +761,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       }
     }
     __syncthreads();
+    STAMP(10);
   }
 }
 
@@ -597,5 +825,9 @@ hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStrea
   if (matches<ShapeTiny1>(s)) return launch_patch<ShapeTiny1>(mode, a, st);
   return hipErrorInvalidValue;
 }
+
+#ifdef DMF_STAMPS
+hipError_t set_stamps(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#endif
 
 }  // namespace dmf

@@ -18,14 +18,12 @@ struct Shape {
   static constexpr int PB = SP * SP;        // aux pixels per patch
   static constexpr int TB = C2 * S * S;     // taps of the lift conv
   static constexpr int F2 = 2 * F;
-  // threads per workgroup: 8 wave64 (2 per SIMD; one workgroup per CU), more only when a patch has
-  // more than 512 (channel,row) pairs
-  static constexpr int NT = (F * P <= 512) ? 512 : ((F * P + 63) / 64) * 64;
+  // threads per workgroup (one workgroup per CU): one 16-lane row group per feature channel, so that every
+  // reduction over patch rows is a 4-step shuffle inside a wavefront; at least 512 (head mapping)
+  static constexpr int NT = (F * 16 <= 512) ? 512 : ((F * 16 + 63) / 64) * 64;
   static constexpr int NW = NT / 64;
-  // LDS row strides (floats).  (Cs/4) odd makes a 16-lane ds_read_b128 group with lane<->pixel hit 64
-  // distinct banks (MI355X_MICROARCH.md §LDS); Y1 rows are read lane<->channel, so they need no pad.
-  static constexpr int Cs = C + ((((C / 4) & 1) == 0) ? 4 : 0);
-  static constexpr int Fs = F;
+  // LDS row stride of the Y1 maps (floats); the X-tile stride is chosen in Lds<> (dmf_patch_kernel.hip)
+  static constexpr int Fs = F + 1;          // odd: (channel,row)-mapped b32 reads of Y1 spread over all banks
   // flat parameter offsets (floats) — order documented in include/dmf.h
   static constexpr int oA1w = 0;
   static constexpr int oA1b = oA1w + F * Cg;
@@ -44,8 +42,8 @@ struct Shape {
   static_assert(C % G == 0 && F % G == 0, "groups must divide C and F");
   static_assert(Cg % 4 == 0, "bands per group must be a multiple of 4 (16-byte chunks)");
   static_assert(F % 4 == 0, "feature width must be a multiple of 4");
-  static_assert(P <= 32, "row masks are 32-bit");
-  static_assert(F * P <= NT && NT <= 1024, "one thread per (channel,row)");
+  static_assert(P <= 16, "one 16-lane group holds the rows of a patch");
+  static_assert(F * 16 <= NT && NT <= 1024, "one 16-lane row group per channel");
   static_assert(H * 8 <= NT && H <= 64 && 4 * F2 <= NT, "head mapping");
 };
 

@@ -1,0 +1,208 @@
+"""Resident-scene training / evaluation engine (the fast path behind the solvers).
+
+What it removes from the reference's hot loop (solver/mainsolver.py:49-58):
+  * per-item host patch slicing + 3 H2D copies per step  -> padded scenes live in HBM, patches are
+    gathered on-device from pixel coordinates (`dmf_input` mode 1);
+  * forward / CE / backward / Adam as separate framework ops -> two launches per step
+    (`dmf_train_fwd_bwd`, `dmf_grad_reduce_adam`);
+  * `loss.item()` every step                               -> per-step mean loss kept on the device;
+  * per-launch host work                                   -> an epoch plan (shuffled coordinates + labels) is
+    uploaded once and a captured hipGraph of `steps_per_graph` steps is replayed; batch cursor and the
+    Adam step count live in device memory.
+Data parallel (world_size > 1): `dmf_grad_reduce` -> all-reduce(sum) of ONE flat fp32 gradient over RCCL ->
+`dmf_adam_step(grad_scale = 1/world_size)`; identical updates on every rank.
+"""
+import numpy as np
+import torch
+
+from . import lib
+
+
+class Scene:
+    """Padded, normalised scenes resident in HBM: A [Hp, Wp, C], B [HpB, WpB, C2] (pixel-major, fp32)."""
+
+    def __init__(self, primary, aux, device):
+        A = np.ascontiguousarray(primary, dtype=np.float32)
+        Bm = np.ascontiguousarray(aux, dtype=np.float32)
+        if Bm.ndim == 2:
+            Bm = Bm[:, :, None]
+        self.A = torch.from_numpy(A).to(device)
+        self.B = torch.from_numpy(Bm).to(device)
+        self.device = torch.device(device)
+
+
+class TrainEngine:
+    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.net, self.scene, self.B = net, scene, int(batch)
+        self.shape = net.shape
+        lib.shape_supported(self.shape)
+        self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        dev = scene.device
+        self.theta = net.flat_parameters()
+        if self.theta.device != dev:
+            raise lib.DmfError('net and scene must be on the same device')
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.grad = torch.zeros_like(self.theta)
+        K = net.arch['K']
+        self.logits = torch.empty(self.B, K, device=dev)
+        self.loss = torch.zeros(self.B, device=dev)
+        self.ws = torch.empty(lib.workspace_bytes(self.shape, self.B) // 4, device=dev)
+        self.step_count = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        # device-side bookkeeping for graph replay
+        self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.plan_xy = self.plan_labels = self.loss_hist = None
+        self.graph = None
+        self.graph_steps = 0
+
+    # ------------------------------------------------------------------ eager step (host-side step count)
+    def step(self, xy, labels):
+        """One optimiser step on the patches at `xy` [B,2] int32 (device) with `labels` [B] int32 (device)."""
+        if xy.shape[0] != self.B:
+            raise lib.DmfError('engine was built for batch %d, got %d' % (self.B, xy.shape[0]))
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
+        self._launch(inp, labels, None, None)
+
+    def step_patches(self, a, b, labels):
+        """Same step from materialised patch tensors (the reference dataloader's batch)."""
+        inp = lib.input_patches(self.shape, a, b)
+        self._launch(inp, labels, None, None)
+
+    def _launch(self, inp, labels, dev_step, dev_cursor, loss_hist=None):
+        self.step_count += 1
+        theta = self.theta
+        nB = inp.B
+        lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
+                          adam_step_dev=dev_step)
+        if self.world == 1:
+            lib.grad_reduce_adam(self.shape, nB, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
+                                 self.step_count, adam_step_dev=dev_step, cursor_dev=dev_cursor,
+                                 loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
+        else:
+            import torch.distributed as dist
+            lib.grad_reduce(self.shape, nB, self.ws, self.grad)
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            lib.adam_step(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count,
+                          grad_scale=1.0 / self.world, adam_step_dev=dev_step, cursor_dev=dev_cursor)
+
+    # ------------------------------------------------------------------ epoch plan + hipGraph replay
+    def load_plan(self, xy_all, labels_all):
+        """Upload an epoch's shuffled stream: xy_all [n*B, 2], labels_all [n*B] (host or device, any int type)."""
+        dev = self.scene.device
+        xy = torch.as_tensor(xy_all).to(device=dev, dtype=torch.int32).contiguous()
+        lab = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
+        if xy.shape[0] % self.B or xy.shape[0] != lab.shape[0]:
+            raise lib.DmfError('plan length must be a multiple of the batch size')
+        xy_host = xy.cpu().numpy()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_host)
+        K = self.net.arch['K']
+        if int(lab.min()) < 0 or int(lab.max()) >= K:
+            raise lib.DmfError('label outside [0, %d)' % K)
+        n = xy.shape[0] // self.B
+        same = self.plan_xy is not None and self.plan_xy.shape == xy.shape
+        if same:                                   # keep addresses stable for an already captured graph
+            self.plan_xy.copy_(xy); self.plan_labels.copy_(lab)
+        else:
+            self.plan_xy, self.plan_labels = xy, lab
+            self.loss_hist = torch.zeros(n, device=dev)
+            self.graph = None
+        self.dev_cursor.zero_()
+        self.dev_step.fill_(self.step_count)
+        self.plan_steps = n
+        return n
+
+    def _plan_step(self):
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=self.B, cursor=self.dev_cursor)
+        self._launch(inp, self.plan_labels, self.dev_step, self.dev_cursor, self.loss_hist)
+
+    def run_plan(self, steps=None, steps_per_graph=0):
+        """Run `steps` steps of the loaded plan (default: all).  steps_per_graph > 0 replays a captured hipGraph
+        (single-GPU only); 0 launches eagerly.  No host synchronisation."""
+        steps = self.plan_steps if steps is None else steps
+        done = 0
+        if steps_per_graph > 0 and self.world == 1:
+            if self.graph is None or self.graph_steps != steps_per_graph:
+                self._capture(steps_per_graph)
+            while steps - done >= steps_per_graph:
+                self.graph.replay()
+                self.step_count += steps_per_graph
+                done += steps_per_graph
+        for _ in range(steps - done):
+            self._plan_step()
+        return steps
+
+    def _capture(self, n):
+        # one eager warm-up step on a side stream state copy is not needed: the kernels were already launched
+        # (hipFuncSetAttribute is not capturable), so make sure of that first
+        count0 = self.step_count
+        saved = [t.clone() for t in (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)]
+        self._plan_step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                self._plan_step()
+        # capture executed nothing, the warm-up did: restore the exact pre-capture state
+        for t, s in zip((self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist), saved):
+            t.copy_(s)
+        self.step_count = count0
+        self.graph, self.graph_steps = g, n
+
+    def mean_losses(self):
+        """Per-step mean CE of the plan steps run so far (one D2H copy)."""
+        return self.loss_hist[:int(self.dev_cursor.item())].cpu()
+
+
+class EvalEngine:
+    """Forward + argmax + on-device confusion matrix / label map (mainsolver.py:102-147,164-197)."""
+
+    def __init__(self, net, scene, batch):
+        self.net, self.scene, self.B = net, scene, int(batch)
+        self.shape = net.shape
+        lib.shape_supported(self.shape)
+        dev = scene.device
+        K = net.arch['K']
+        self.logits = torch.empty(self.B, K, device=dev)
+        self.pred = torch.empty(self.B, dtype=torch.int32, device=dev)
+
+    def predict(self, xy):
+        """xy [n,2] int32 device -> (logits [n,K], pred [n]) views valid until the next call."""
+        n = xy.shape[0]
+        if n > self.B:
+            raise lib.DmfError('batch larger than the engine was built for')
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
+        lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits, self.pred)
+        return self.logits[:n], self.pred[:n]
+
+    def confusion(self, xy_all, labels_all, matrix=None):
+        """Confusion matrix [K,K] int64 (rows = prediction) over all given pixels; one D2H at the end."""
+        dev = self.scene.device
+        K = self.net.arch['K']
+        xy_all = torch.as_tensor(xy_all).to(device=dev, dtype=torch.int32).contiguous()
+        labels_all = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_all.cpu().numpy())
+        if matrix is None:
+            matrix = torch.zeros(K, K, dtype=torch.int64, device=dev)
+        for i in range(0, xy_all.shape[0], self.B):
+            xy = xy_all[i:i + self.B]
+            _, pred = self.predict(xy)
+            lib.confusion_accum(pred, labels_all[i:i + self.B], K, matrix)
+        return matrix
+
+    def label_map(self, xy_all, H, W, label_map=None):
+        dev = self.scene.device
+        xy_all = torch.as_tensor(xy_all).to(device=dev, dtype=torch.int32).contiguous()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_all.cpu().numpy())
+        if label_map is None:
+            label_map = torch.zeros(H, W, dtype=torch.int32, device=dev)
+        for i in range(0, xy_all.shape[0], self.B):
+            xy = xy_all[i:i + self.B]
+            _, pred = self.predict(xy)
+            lib.labelmap_write(pred, xy, W, label_map)
+        return label_map

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdmf_hip.so')
+LIB_PATH = os.environ.get('DMF_LIB', os.path.join(_HERE, 'libdmf_hip.so'))   # DMF_LIB: diagnostic builds only
 KMAX = 64
 
 
@@ -23,7 +23,7 @@ class Shape(C.Structure):
 
 class Input(C.Structure):
     _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('a', C.c_void_p), ('b', C.c_void_p), ('sceneA', C.c_void_p),
-                ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32)]
+                ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32), ('cursor', C.c_void_p)]
 
 
 def _load():
@@ -40,11 +40,11 @@ def _load():
         'dmf_param_layout': (i32, [SP, C.POINTER(i64)]),
         'dmf_workspace_bytes': (i64, [SP, i32]),
         'dmf_forward': (i32, [SP, IP, vp, vp, vp, vp, vp]),
-        'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp]),
+        'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
         'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
-        'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
-        'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp]),
+        'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp]),
+        'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
         'dmf_confusion_accum': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_labelmap_write': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_pan2ms': (i32, [vp, i32, i32, i32, vp, vp]),
@@ -111,18 +111,20 @@ def input_patches(shape, a, b):
     if tuple(a.shape) != (B, shape.C, shape.P, shape.P) or tuple(b.shape) != (B, shape.C2, SP, SP):
         raise DmfError('patch tensors %s / %s do not match shape C=%d P=%d C2=%d S=%d' %
                        (tuple(a.shape), tuple(b.shape), shape.C, shape.P, shape.C2, shape.S))
-    return Input(mode=0, B=B, a=a.data_ptr(), b=b.data_ptr(), sceneA=None, sceneB=None, xy=None, Wp=0, WpB=0)
+    return Input(mode=0, B=B, a=a.data_ptr(), b=b.data_ptr(), sceneA=None, sceneB=None, xy=None, Wp=0, WpB=0, cursor=None)
 
 
-def input_gather(shape, sceneA, sceneB, xy):
-    """mode 1: sceneA [Hp,Wp,C], sceneB [HpB,WpB,C2] resident padded scenes, xy [B,2] int32 top-left pixels."""
+def input_gather(shape, sceneA, sceneB, xy, B=None, cursor=None):
+    """mode 1: sceneA [Hp,Wp,C], sceneB [HpB,WpB,C2] resident padded scenes, xy [B,2] int32 top-left pixels.
+    With `cursor` (device int32[1]) xy is a whole epoch plan [n_steps*B, 2] and `B` the batch size."""
     _dev(sceneA, torch.float32, 'sceneA'); _dev(sceneB, torch.float32, 'sceneB'); _dev(xy, torch.int32, 'xy')
     if sceneA.dim() != 3 or sceneA.shape[2] != shape.C or sceneB.dim() != 3 or sceneB.shape[2] != shape.C2:
         raise DmfError('scene tensors must be [Hp,Wp,C] and [HpB,WpB,C2]')
     if xy.dim() != 2 or xy.shape[1] != 2:
         raise DmfError('xy must be [B,2]')
-    return Input(mode=1, B=xy.shape[0], a=None, b=None, sceneA=sceneA.data_ptr(), sceneB=sceneB.data_ptr(),
-                 xy=xy.data_ptr(), Wp=sceneA.shape[1], WpB=sceneB.shape[1])
+    return Input(mode=1, B=xy.shape[0] if B is None else B, a=None, b=None, sceneA=sceneA.data_ptr(),
+                 sceneB=sceneB.data_ptr(), xy=xy.data_ptr(), Wp=sceneA.shape[1], WpB=sceneB.shape[1],
+                 cursor=None if cursor is None else cursor.data_ptr())
 
 
 def check_xy_bounds(shape, sceneA, sceneB, xy_host):
@@ -139,9 +141,9 @@ def forward(shape, inp, theta, pool_w, logits, pred=None):
     check(_lib.dmf_forward(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(logits), _ptr(pred), _stream()))
 
 
-def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws):
+def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, adam_step_dev=None):
     check(_lib.dmf_train_fwd_bwd(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels),
-                                 C.c_float(loss_scale), _ptr(logits), _ptr(loss), _ptr(ws), _stream()))
+                                 C.c_float(loss_scale), _ptr(logits), _ptr(loss), _ptr(ws), _ptr(adam_step_dev), _stream()))
 
 
 def backward_dlogits(shape, inp, theta, pool_w, dlogits, ws):
@@ -152,14 +154,16 @@ def grad_reduce(shape, B, ws, grad):
     check(_lib.dmf_grad_reduce(C.byref(shape), B, _ptr(ws), _ptr(grad), _stream()))
 
 
-def adam_step(theta, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+def adam_step(theta, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0, adam_step_dev=None, cursor_dev=None):
     check(_lib.dmf_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), lr, b1, b2, eps, step,
-                             grad_scale, _stream()))
+                             grad_scale, _ptr(adam_step_dev), _ptr(cursor_dev), _stream()))
 
 
-def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step):
+def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step, adam_step_dev=None, cursor_dev=None,
+                     loss=None, loss_hist=None):
     check(_lib.dmf_grad_reduce_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), _ptr(grad),
-                                    lr, b1, b2, eps, step, _stream()))
+                                    lr, b1, b2, eps, step, _ptr(adam_step_dev), _ptr(cursor_dev), _ptr(loss),
+                                    _ptr(loss_hist), _stream()))
 
 
 def confusion_accum(pred, target, K, matrix):

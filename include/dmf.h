@@ -54,6 +54,10 @@ typedef struct dmf_input {
   const int32_t* xy;   /* [B, 2] top-left pixel (x = row, y = col) of each patch (dataset.py:171-172) */
   int32_t Wp;          /* row pitch of sceneA in pixels                                            */
   int32_t WpB;         /* row pitch of sceneB in pixels                                            */
+  /* optional (mode 1): device int holding the index of the current batch inside a pre-uploaded epoch plan;
+     when non-NULL, patch b reads xy[(*cursor)*B + b] and labels[(*cursor)*B + b].  Lets a captured
+     hipGraph of many steps be replayed without host-side pointer updates. */
+  const int32_t* cursor;
 } dmf_input;
 
 int32_t dmf_version(void);
@@ -86,7 +90,9 @@ int32_t dmf_forward(const dmf_shape* shape, const dmf_input* in, const float* th
  * gradient slabs and head vectors in `workspace` for dmf_grad_reduce*. */
 int32_t dmf_train_fwd_bwd(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                           const int32_t* labels, float loss_scale,
-                          float* logits, float* loss, void* workspace, void* stream);
+                          float* logits, float* loss, void* workspace, int32_t* adam_step_dev, void* stream);
+/* adam_step_dev (may be NULL): device int incremented by one per call (the optimiser step count a later
+ * dmf_grad_reduce_adam / dmf_adam_step on the same stream reads instead of its host `step` argument). */
 
 /* Backward for a caller-supplied dL/dlogits [B, K] (the autograd path: torch computes the loss). */
 int32_t dmf_backward_dlogits(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
@@ -99,12 +105,19 @@ int32_t dmf_grad_reduce(const dmf_shape* shape, int32_t B, const void* workspace
  * betas 0.9/0.999, eps 1e-8, no weight decay).  step = 1-based step count.  grad_scale multiplies grad
  * first (1/world_size after an all-reduce(sum)). */
 int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n,
-                      float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+                      float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                      const int32_t* adam_step_dev, int32_t* cursor_dev, void* stream);
+/* adam_step_dev (may be NULL): when given, the step count is read from the device instead of `step`.
+ * cursor_dev (may be NULL): device int advanced by one (the epoch-plan cursor of dmf_input). */
 
 /* dmf_grad_reduce + dmf_adam_step in one launch (single-GPU step). grad may be NULL. */
 int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* workspace,
                              float* theta, float* m, float* v, float* grad,
-                             float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+                             float lr, float beta1, float beta2, float eps, int32_t step,
+                             const int32_t* adam_step_dev, int32_t* cursor_dev,
+                             const float* loss, float* loss_hist, void* stream);
+/* loss / loss_hist (may be NULL): when both are given, loss_hist[cursor] = mean(loss[0..B)) (fixed-order sum),
+ * i.e. the value the reference prints per step (`loss.item()`, mainsolver.py:58) without a host sync. */
 
 /* Replaces the per-sample `.item()` loop `test_matrix[pred][target] += 1` (mainsolver.py:140-141):
  * matrix [K, K] int64, rows = prediction. */
