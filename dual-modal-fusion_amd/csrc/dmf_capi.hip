@@ -53,8 +53,6 @@ static int check(hipError_t e, const char* what) {
 static Layout layout_of(const dmf_shape& s) { return make_layout(s.C, s.C2, s.P, s.S, s.F, s.G, s.H, s.K); }
 
 // ------------------------------------------------------------------------------ gradient reduction (+Adam)
-// One thread-row of 32 consecutive parameters x 8 batch chunks per 256-thread block; chunk partials are
-// combined through LDS in fixed order, so the result is independent of scheduling.
 //   conv params  : grad[p] = sum_blk slab[blk][p]
 //   fc1.weight   : grad = sum_b dh[b][j] * z[b][i]      fc1.bias: sum_b dh[b][j]
 //   fc2.weight   : grad = sum_b dl[b][k] * h[b][j]      fc2.bias: sum_b dl[b][k]
@@ -89,54 +87,91 @@ __device__ __forceinline__ void adam_update(float* theta, float* m, float* v, in
   theta[p] -= (lr / bc1) * (mn / denom);
 }
 
+// Block layout: 16 consecutive parameters x 16 batch chunks (256 threads).  Every thread issues its chunk's loads
+// back to back (16 per pass), chunk partials are combined through LDS in a fixed tree, so the result does not
+// depend on scheduling.  The last block does the bookkeeping (per-step mean loss, epoch-plan cursor).
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
-  __shared__ float part[8][32];
-  const int jj = threadIdx.x & 31, ch = threadIdx.x >> 5;
-  if (blockIdx.x == 0 && threadIdx.x == 64) {        // bookkeeping lane: per-step mean loss, cursor advance
+  __shared__ float part[16][17];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {                 // bookkeeping block
     const int cur = a.cursor_dev != nullptr ? *a.cursor_dev : 0;
     if (a.loss != nullptr && a.loss_hist != nullptr) {
       float s = 0.f;
-      for (int b = 0; b < a.B; ++b) s += a.loss[b];
-      a.loss_hist[cur] = s / (float)a.B;
+      for (int b = tid; b < a.B; b += 256) s += a.loss[b];
+      float* red = &part[0][0];
+      red[tid] = s;
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+      }
+      if (tid == 0) a.loss_hist[cur] = red[0] / (float)a.B;
     }
-    if (a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
+    if (tid == 0 && a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
+    return;
   }
-  const int64_t p = (int64_t)blockIdx.x * 32 + jj;
+  const int jj = tid & 15, ch = tid >> 4;
+  const int64_t p = (int64_t)blockIdx.x * 16 + jj;
   float acc = 0.f;
   if (p < a.n) {
     if (p < a.NCONV) {
-      const int per = (a.nblk + 7) / 8;
+      const int per = (a.nblk + 15) / 16;
       const int lo = ch * per, hi = min(a.nblk, lo + per);
-      for (int b = lo; b < hi; ++b) acc += a.slab[(size_t)b * a.SLAB + p];
+      for (int b0 = lo; b0 < hi; b0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (b0 + i < hi) ? a.slab[(size_t)(b0 + i) * a.SLAB + p] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += v[i];
+      }
     } else {
-      const int per = (a.B + 7) / 8;
+      const int per = (a.B + 15) / 16;
       const int lo = ch * per, hi = min(a.B, lo + per);
+      const float* u; const float* w; int su, sw, ou, ow;   // acc += u[b*su + ou] * w[b*sw + ow]  (w == nullptr: * 1)
       if (p < a.oFc1b) {
         const int q = (int)(p - a.oFc1w), j = q / a.F2, i = q - j * a.F2;
-        for (int b = lo; b < hi; ++b) acc = fmaf(a.dh[(size_t)b * a.H + j], a.z[(size_t)b * a.F2 + i], acc);
+        u = a.dh; su = a.H; ou = j; w = a.z; sw = a.F2; ow = i;
       } else if (p < a.oFc2w) {
-        const int j = (int)(p - a.oFc1b);
-        for (int b = lo; b < hi; ++b) acc += a.dh[(size_t)b * a.H + j];
+        u = a.dh; su = a.H; ou = (int)(p - a.oFc1b); w = nullptr; sw = 0; ow = 0;
       } else if (p < a.oFc2b) {
         const int q = (int)(p - a.oFc2w), k = q / a.H, j = q - k * a.H;
-        for (int b = lo; b < hi; ++b) acc = fmaf(a.dl[(size_t)b * KMAX + k], a.h[(size_t)b * a.H + j], acc);
+        u = a.dl; su = KMAX; ou = k; w = a.h; sw = a.H; ow = j;
       } else {
-        const int k = (int)(p - a.oFc2b);
-        for (int b = lo; b < hi; ++b) acc += a.dl[(size_t)b * KMAX + k];
+        u = a.dl; su = KMAX; ou = (int)(p - a.oFc2b); w = nullptr; sw = 0; ow = 0;
+      }
+      for (int b0 = lo; b0 < hi; b0 += 16) {
+        float x[16], y[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool in = b0 + i < hi;
+          x[i] = in ? u[(size_t)(b0 + i) * su + ou] : 0.f;
+          y[i] = (w != nullptr) ? (in ? w[(size_t)(b0 + i) * sw + ow] : 0.f) : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = fmaf(x[i], y[i], acc);
       }
     }
   }
   part[ch][jj] = acc;
+  __shared__ float bcs[2];
+  if (tid == 255 && a.theta != nullptr) {            // one thread per block forms the bias corrections
+    float bc1 = a.bc1, bc2s = a.bc2_sqrt;
+    if (a.step_dev != nullptr) bias_corrections(*a.step_dev, a.b1, a.b2, bc1, bc2s);
+    bcs[0] = bc1;
+    bcs[1] = bc2s;
+  }
   __syncthreads();
   if (ch == 0 && p < a.n) {
-    const float g = ((part[0][jj] + part[1][jj]) + (part[2][jj] + part[3][jj])) +
-                    ((part[4][jj] + part[5][jj]) + (part[6][jj] + part[7][jj]));
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = part[i][jj];
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int i = 0; i < w; ++i) t[i] += t[i + w];
+    const float g = t[0];
     if (a.grad != nullptr) a.grad[p] = g;
-    if (a.theta != nullptr) {
-      float bc1 = a.bc1, bc2s = a.bc2_sqrt;
-      if (a.step_dev != nullptr) bias_corrections(*a.step_dev, a.b1, a.b2, bc1, bc2s);
-      adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, bc1, bc2s);
-    }
+    if (a.theta != nullptr) adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, bcs[0], bcs[1]);
   }
 }
 
@@ -290,7 +325,7 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
     }
   }
   a.step_dev = step_dev; a.cursor_dev = cursor_dev; a.loss = loss; a.loss_hist = loss_hist;
-  const int grid = (int)((L.n_params + 31) / 32);
+  const int grid = (int)((L.n_params + 15) / 16) + 1;   // + the bookkeeping block
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check(hipGetLastError(), "grad_reduce launch");
 }

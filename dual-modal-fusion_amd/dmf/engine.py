@@ -64,8 +64,8 @@ class TrainEngine:
     # ------------------------------------------------------------------ eager step (host-side step count)
     def step(self, xy, labels):
         """One optimiser step on the patches at `xy` [B,2] int32 (device) with `labels` [B] int32 (device)."""
-        if xy.shape[0] != self.B:
-            raise lib.DmfError('engine was built for batch %d, got %d' % (self.B, xy.shape[0]))
+        if xy.shape[0] > self.B:
+            raise lib.DmfError('engine was built for batches of at most %d, got %d' % (self.B, xy.shape[0]))
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
         self._launch(inp, labels, None, None)
 

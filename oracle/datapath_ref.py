@@ -55,8 +55,8 @@ def split_data_old(label, size):
 def dataset_dual_item(MS, PAN, xyl, index, patch_size, scale=4):
     """train/dataset.py:168-185 — (ms[C,p,p] f32, pan[1,sp,sp] f32, label 0-dim f32, x:int, y:int)."""
     p = patch_size
-    x = int(xyl[0][index])
-    y = int(xyl[1][index])
+    x = int(np.asarray(xyl[0][index]).reshape(-1)[0])
+    y = int(np.asarray(xyl[1][index]).reshape(-1)[0])
     ms = MS[x:x + p, y:y + p, :].transpose((2, 0, 1))
     pan = PAN[scale * x:scale * x + scale * p, scale * y:scale * y + scale * p]
     pan = pan[None] if pan.ndim == 2 else pan.transpose((2, 0, 1))

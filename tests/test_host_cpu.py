@@ -1,0 +1,237 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol of include/dmf.h, the
+reference-mirror modules (config, function, dataset, kappa, IHS, qua_loss, solver splits) against the golden
+fixtures captured from the real reference, and the data-parallel gradient plumbing over gloo (world_size 2)."""
+import json
+import os
+import re
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'dual-modal-fusion_amd')
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, 'include', 'dmf.h')).read()
+    declared = set(re.findall(r'\b(dmf_[a-z0-9_]+)\s*\(', hdr))
+    from dmf import lib
+    assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
+    import ctypes
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert lib.version() == 100
+
+
+def test_param_layout_and_workspace():
+    from dmf import lib
+    from model.gmfnet import Net, PARAM_ORDER
+    cfg = {'patch_size': 11, 'Categories_Number': 17, 'data_city': 's', 'DATA_DICT': {'s': {'size': [9, 9, 200]}},
+           'scale': 1, 'aux_bands': 1}
+    net = Net(cfg)
+    assert net.arch['G'] == 10 and net.arch['F'] == 40
+    off = net._offsets
+    sd = net.state_dict()
+    assert [k for k in sd.keys() if k != 'pool_w'] == list(PARAM_ORDER) and 'pool_w' in sd
+    for i, k in enumerate(PARAM_ORDER):
+        assert off[i + 1] - off[i] == sd[k].numel()
+    assert off[16] == 8009
+    assert lib.workspace_bytes(net.shape, 256) > 0
+    flat = net.flat_parameters()
+    with torch.no_grad():
+        net.fc2.bias.add_(1.0)                       # parameters are views of the flat vector
+    assert torch.equal(flat[off[11]:off[12]], net.fc2.bias.detach())
+    lib.shape_supported(net.shape)
+    bad = dict(cfg, patch_size=7)
+    with pytest.raises(lib.DmfError):
+        lib.shape_supported(Net(bad).shape)
+
+
+def test_function_module_against_goldens(golden_dir):
+    from function.function import data_padding, data_padding_aux, split_data_old, to_tensor
+    g1 = _g(golden_dir, 'g1_to_tensor.npz')
+    assert np.array_equal(to_tensor(g1['cube']), g1['out'])
+    g2 = _g(golden_dir, 'g2_split.npz')
+    m, idx = split_data_old(g2['label'], {'DATA_DICT': {'t': {'size': [7, 9, 5]}}, 'data_city': 't'})
+    assert all(np.array_equal(a, g2[k]) and a.dtype == np.float64 for a, k in zip(m, 'xyl'))
+    assert idx[0] == g2['idx0'].tolist() and idx[1] == g2['idx1'].tolist()
+    cube = np.arange(6 * 7 * 3, dtype=np.float64).reshape(6, 7, 3)
+    assert data_padding(cube, {'patch_size': 4}, 'ms').shape == (9, 10, 3)
+    pan = np.arange(24 * 28, dtype=np.float64).reshape(24, 28)
+    assert data_padding(pan, {'patch_size': 4}, 'pan').shape == (24 + 15, 28 + 15)            # reference: 4*patch-1
+    assert data_padding(pan, {'patch_size': 4, 'scale': 1}, 'pan').shape == (27, 31)
+    assert data_padding_aux(np.zeros((6, 7, 3)) + np.arange(3), {'patch_size': 4, 'scale': 1}).shape == (9, 10, 3)
+    p = data_padding(cube, {'patch_size': 3}, 'ms')
+    assert np.array_equal(p[6], p[4]) and np.array_equal(p[:, 7], p[:, 5])                    # reflect-101
+
+
+def test_dataset_against_golden(golden_dir):
+    from train.dataset import dataset_dual
+    g = _g(golden_dir, 'g3_dataset.npz')
+    g2 = _g(golden_dir, 'g2_split.npz')
+    ds = dataset_dual(g['MS'], g['PAN'], [g2['x'], g2['y'], g2['l']], {'patch_size': int(g['patch'])})   # scale defaults to 4
+    assert len(ds) == int(g['length'])
+    for n, i in enumerate(g['idx']):
+        ms, pan, l, x, y = ds[int(i)]
+        assert np.array_equal(ms.numpy(), g[f'ms{n}']) and np.array_equal(pan.numpy(), g[f'pan{n}'])
+        assert l.dtype == torch.float32 and l.dim() == 0 and float(l) == float(g[f'l{n}'])
+        assert isinstance(x, int) and isinstance(y, int) and [x, y] == g[f'xy{n}'].tolist()
+    iv = ds.index_view()
+    assert iv[10] == (int(g2['x'][10, 0]), int(g2['y'][10, 0]), int(g2['l'][10, 0]), 10)
+
+
+def test_kappa_ihs_qualoss_against_goldens(golden_dir):
+    from image_convert.IHS import IHS_tran, pan2ms, unsampling
+    from indicators.kappa import aa_oa, kappa
+    from train.loss_function import qua_loss
+    g6 = json.load(open(os.path.join(golden_dir, 'g6_kappa.json')))
+    for e in g6.values():
+        aa, oa, k, disp = aa_oa(np.array(e['matrix'], dtype=np.float64))
+        assert abs(k - e['kappa']) < 1e-12 and abs(aa - e['aa']) < 1e-12 and abs(oa - e['oa']) < 1e-12
+        assert abs(kappa(np.array(e['matrix'], dtype=np.float64)) - e['kappa']) < 1e-12
+    g7 = _g(golden_dir, 'g7_ihs.npz')
+    assert np.array_equal(unsampling(g7['pan'], 2), g7['un2'])
+    assert np.array_equal(pan2ms(g7['pan'], [4, 4, 4]), g7['p2m'])
+    assert np.array_equal(pan2ms(g7['pan_r'], [3, 5, 4]), g7['p2m_r'])
+    assert np.allclose(IHS_tran(g7['ihs_ms'], g7['ihs_pan'], np.random.default_rng(0)), g7['ihs_pan'], atol=1e-12)
+    g8 = _g(golden_dir, 'g8_qua_loss.npz')
+    x = torch.from_numpy(g8['logits']).requires_grad_(True)
+    loss = qua_loss()(x, 10, torch.from_numpy(g8['target']), {'dqtl': json.loads(str(g8['cfg']))})
+    loss.backward()
+    assert abs(loss.item() - float(g8['loss'])) < 1e-6 and np.allclose(x.grad.numpy(), g8['grad'], atol=1e-7)
+
+
+def test_utils_factories_match_reference_defaults(golden_dir):
+    from utils.utils import adam_hparams, epoch_lr, make_loss, make_optimizer, make_scheduler
+    g = _g(golden_dir, 'g5_ce_adam.npz')
+    cfg = {'schedule': {'optimizer': 'ADAM', 'lr': 1e-3, 'base_lr': 5e-4, 'if_scheduler': 1, 'scheduler': 'ExponentialLR',
+                        'loss': 'Criterion'}, 'epoch': 5}
+    w = torch.nn.Parameter(torch.from_numpy(g['w0']).clone())
+    opt = make_optimizer(cfg, [w])
+    d = json.loads(str(g['adam_defaults']))
+    assert opt.defaults['lr'] == d['lr'] and list(opt.defaults['betas']) == d['betas'] and opt.defaults['eps'] == d['eps']
+    assert adam_hparams(cfg) == (1e-3, (0.9, 0.999), 1e-8)
+    gr = torch.from_numpy(np.load(os.path.join(golden_dir, 'g5_adam_g0.npy')))
+    for step in range(3):
+        w.grad = gr.clone()
+        opt.step()
+        assert np.allclose(w.detach().numpy(), g['adam_traj'][step], atol=1e-7)
+        gr = gr * 0.5 + 0.1
+    ce = make_loss('Criterion', cfg)
+    assert abs(ce(torch.from_numpy(g['logits']), torch.from_numpy(g['target']).long()).item() - float(g['ce'])) < 1e-6
+    sch = make_scheduler(make_optimizer(cfg, [torch.nn.Parameter(torch.zeros(1))]), cfg)
+    assert sch is not None and np.allclose([epoch_lr(cfg, e) for e in range(1, 5)], g['exp_lrs'], rtol=1e-12)
+
+
+def _golden_scene_dir(golden_dir, tmp):
+    g = _g(golden_dir, 'g9_trajectory.npz')
+    d = os.path.join(tmp, 'scene') + '/'
+    os.makedirs(d)
+    np.save(d + 'ms4.tif.npy', g['primary']); np.save(d + 'pan.tif.npy', g['aux']); np.save(d + 'label.npy', g['label'])
+    cfg = json.loads(str(g['cfg']))
+    cfg.update(data_address=d, RESULT_output=os.path.join(tmp, 'out') + '/', RESULT_excel=os.path.join(tmp, 'r.xlsx'), nohup=1)
+    os.makedirs(cfg['RESULT_output'])
+    return g, cfg
+
+
+def test_solver_split_and_first_epoch_order_match_reference(golden_dir):
+    """BaseSolver.dataloader + the index-only loader consume the global RNG exactly like the reference's loaders
+    (G4): same train/test/valid split, same first-epoch visit order under torch.manual_seed(3407)."""
+    from solver.mainsolver import Solver
+    tmp = tempfile.mkdtemp(prefix='dmf_cpu_')
+    try:
+        g, cfg = _golden_scene_dir(golden_dir, tmp)
+        cfg['device'] = 'cpu'
+        torch.manual_seed(3407)
+        s = Solver(cfg)
+        assert s.fast is False
+        s.dataloader()
+        assert np.array_equal(np.array(s.matrix_[1]), g['labelled'])
+        base = g['labelled']
+        assert np.array_equal(np.array(s.train_loader.dataset.indices), base[g['split_train']])
+        assert np.array_equal(np.array(s.test_loader.dataset.indices), base[g['split_test']])
+        assert np.array_equal(np.array(s.valid_loader.dataset.indices), base[g['split_valid']])
+        n_train = len(g['split_train'])
+        s.init_model()                 # as Solver.train does first (mainsolver.py:44): parameter init draws from the RNG
+        for k, v in s.model.state_dict().items():
+            assert np.array_equal(v.numpy(), g['init.' + k]), k          # same seeded initial weights as the reference run
+        seen = []
+        for x, y, lab, idx in s.train_index_loader:
+            seen += idx.tolist()
+        assert seen == g['visit_order'][:n_train].tolist()
+        # the materialising twin yields the reference's batch structure
+        b = next(iter(s.valid_loader))
+        assert b[0].shape[1:] == (8, 5, 5) and b[1].shape[1:] == (1, 20, 20) and b[2].dtype == torch.float32 and b[3].dtype == torch.int64
+    finally:
+        shutil.rmtree(tmp)
+
+
+def test_config_loader_roundtrip():
+    from utils.config import get_render_config
+    tmp = tempfile.mkdtemp(prefix='dmf_cfg_')
+    try:
+        src = open(os.path.join(PKG, 'config.yml')).read().replace('../Export_result/', tmp + '/Export_result/')
+        path = os.path.join(tmp, 'my_config.yml')
+        open(path, 'w').write(src)
+        cfg = get_render_config(path)
+        assert cfg['Categories_Number'] == 17 and isinstance(cfg['schedule']['lr'], float)
+        assert cfg['RESULT_output'].endswith('gmfnet__0_output/') and os.path.isdir(cfg['RESULT_output'])
+        assert cfg['data_address'].endswith('syn145/') and cfg['scale'] == 1
+        cfg2 = get_render_config(path)                     # output dir exists now -> next free number
+        assert cfg2['FILE_NUM'] == 1 and cfg2['RESULT_output'].endswith('gmfnet__1_output/')
+    finally:
+        shutil.rmtree(tmp)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path[:0] = [PKG, REPO]
+    from dmf.parallel import allreduce_mean_, shard_batch
+    from oracle.gmfnet_ref import Net as RefNet
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [9, 9, 8]}}, 'scale': 1, 'aux_bands': 1}
+    torch.manual_seed(0)
+    net = RefNet(cfg)
+    g = torch.Generator().manual_seed(1)
+    a, b, t = torch.rand(8, 8, 5, 5, generator=g), torch.rand(8, 1, 5, 5, generator=g), torch.randint(0, 5, (8,), generator=g)
+    lo, hi = shard_batch(8, rank, world)
+    loss = torch.nn.functional.cross_entropy(net(a[lo:hi], b[lo:hi]), t[lo:hi])
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    allreduce_mean_(flat, dist.group.WORLD)
+    if rank == 0:
+        q.put(flat.numpy())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_equals_global_batch_gloo():
+    """world_size 2 over gloo: equal contiguous shards, all-reduce(sum) of one flat gradient, x 1/N == the
+    single-process gradient of the global batch (mean-of-means == global mean for equal shards)."""
+    import torch.multiprocessing as mp
+    from oracle.gmfnet_ref import Net as RefNet
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    cfg = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [9, 9, 8]}}, 'scale': 1, 'aux_bands': 1}
+    torch.manual_seed(0)
+    net = RefNet(cfg)
+    g = torch.Generator().manual_seed(1)
+    a, b, t = torch.rand(8, 8, 5, 5, generator=g), torch.rand(8, 1, 5, 5, generator=g), torch.randint(0, 5, (8,), generator=g)
+    torch.nn.functional.cross_entropy(net(a, b), t).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    assert np.allclose(got, want, atol=1e-6)

@@ -1,0 +1,58 @@
+"""Turn the rocprofv3 outputs a GPU run left under gpurun_out/ into the small summaries committed in profiles/.
+
+    python tools/summarize_profiles.py <round-tag>       e.g.  r1
+
+Inputs (produced on the GPU box, see profiles/README.md for the exact commands):
+  gpurun_out/prof_<tag>/**/_kernel_stats.csv        rocprofv3 --kernel-trace --stats      -- python3 bench.py ...
+  gpurun_out/pmc_fetch/**/_counter_collection.csv   rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py ...
+  gpurun_out/pmc_write/**/_counter_collection.csv   rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python3 bench.py ...
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950,
+FETCH_SIZE reports exactly half the bytes of a 16-B-per-lane coalesced read stream (MI355X_MICROARCH.md §HBM),
+which is what the patch kernel's window loads are.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
+    out = os.path.join(ROOT, 'profiles')
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof_' + tag, '**', '*_kernel_stats.csv'), recursive=True)
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w', newline='') as f:
+            csv.writer(f).writerows(rows[:12])
+    pmc = {}
+    for name, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        files = glob.glob(os.path.join(ROOT, 'gpurun_out', name, '**', '*_counter_collection.csv'), recursive=True)
+        if not files:
+            continue
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if r['Counter_Name'] == ctr and 'dmf::' in r['Kernel_Name']:
+                d[r['Kernel_Name']].append(float(r['Counter_Value']))
+        for k, v in d.items():
+            pmc.setdefault(k, {})[ctr] = {'n': len(v), 'median_KiB': statistics.median(v), 'mean_KiB': statistics.mean(v)}
+    summary = {'round': tag, 'kernels': pmc}
+    for k, v in pmc.items():
+        if 'patch_kernel' in k and ', 1>' in k and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            fetch = 2 * v['FETCH_SIZE']['median_KiB'] * 1024
+            write = v['WRITE_SIZE']['median_KiB'] * 1024
+            summary['patch_kernel_hbm_bytes_per_launch'] = fetch + write
+            summary['patch_kernel_fetch_bytes_corrected'] = fetch
+            summary['patch_kernel_write_bytes'] = write
+    json.dump(summary, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
+    json.dump(summary, open(os.path.join(out, tag + '_pmc_traffic.json'), 'w'), indent=1)
+    print(json.dumps(summary, indent=1)[:1500])
+
+
+if __name__ == '__main__':
+    main()
