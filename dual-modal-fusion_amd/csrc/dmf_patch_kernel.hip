@@ -7,23 +7,22 @@
 //
 // Design (gfx950): one workgroup (10 wave64 for F = 40) owns one patch at a time.  The patch window
 // (P*P pixels x C bands, pixel-major) is read from HBM/L2 ONCE with 16-byte coalesced loads issued back to
-// back, and stays in LDS until the last weight gradient has consumed it; every activation lives in LDS or
-// registers; per-thread weights (depthwise taps, fc rows) are loaded into registers once per workgroup.  The
-// only global writes are logits/loss, four small per-patch head vectors and ONE gradient slab row per
-// workgroup.  All reductions are fixed-order (shuffles / ordered LDS sums, no float atomics): a step is
-// bitwise reproducible.
+// back, and stays in LDS until the last weight gradient has consumed it; the two feature maps live in LDS
+// channel-major with 16-byte-aligned rows, so every spatial stage loads whole rows with ds_read_b128 and works
+// from registers.  The only global writes are logits/loss, four small per-patch head vectors and ONE gradient slab
+// row per workgroup.  All reductions are fixed-order (DPP / ordered LDS sums, no float atomics): a step is bitwise
+// reproducible.
 //
 //   P0  gather  X[pix][band]  (a scene row of the window is P*C contiguous floats), aux tile
-//   P1  spec_a  grouped 1x1:  wave-task = (group, 64-pixel half); lane <-> pixel, weights wave-uniform (SGPR)
-//       lift_b  SxS stride-S conv: thread <-> (channel, 16 pixel lanes)
-//   P2  spat_a / spat_b depthwise 3x3: thread <-> (channel, row); the 3x3 window slides along the row in
-//       registers; ReLU masks kept as one word per (channel,row); anchor-Gaussian pooling reduced over the
-//       16 row lanes by shuffles
+//   P1  spec_a  grouped 1x1 and lift_b SxS conv as wave-tasks (channel block, 64-pixel half): lane <-> pixel,
+//       weights wave-uniform in SGPRs (scalar loads through a constant-address-space view of theta)
+//   P2  spat_a / spat_b depthwise 3x3: thread <-> (channel, row): three rows in registers, 99 FMAs, ReLU mask word,
+//       anchor-Gaussian pooling reduced over the 16 row lanes by DPP
 //   P3  head: fc1 / fc2 from register-resident weight rows, softmax-CE by wavefront shuffles, dlogits;
-//       dh and dz re-use the same registers (transposed reduction by shuffles + one ordered LDS sum)
-//   P4  backward of the depthwise stages from the row masks (dY2 = mask * dz[f] * pool[pix]); dW/db reduced
-//       over rows by shuffles -> slab; dY1 rows overwrite Y1 in LDS
-//   P5  lift_b / bias gradients; spec_a weight gradient from the still-resident X tile
+//       dh and dz re-use the same registers (transposed reduction by DPP / permlane swaps + ordered LDS sums)
+//   P4  depthwise backward from the row masks (dY2 = mask * dz[f] * pool[pix]): dW/db (DPP row sums -> slab), then
+//       dY1 rows in place, with the spec_a / lift_b bias and lift_b weight gradients
+//   P5  spec_a weight gradient from the still-resident X tile
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -43,6 +42,13 @@ __device__ unsigned long long* g_stamps = nullptr;
 #else
 #define STAMP(i) do { } while (0)
 #endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global STORE
+// (vmcnt counts stores on gfx950) because of its release fence; inside the patch loop the barriers only hand LDS data
+// between waves — global stores (slab rows, head vectors, logits) are consumed by the NEXT launch — so their
+// round trip must not sit on the critical path.  (The barrier after the LDS-DMA gather stays a __syncthreads():
+// DMA completion is tracked by vmcnt.)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Stops the compiler from hoisting per-thread address arithmetic out of the patch loop (it then spills it).
 #define OPAQUE(v) asm volatile("" : "+v"(v))
@@ -91,6 +97,19 @@ __device__ __forceinline__ float sum16(float v) {         // over the 16 lanes s
   v = DMF_DPP_ADD(v, 0x140);    // row_mirror
   return v;
 }
+__device__ __forceinline__ float swap_add16(float v) {    // v[row] + v[row ^ 1] in every lane (rows of 16 lanes)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float swap_add32(float v) {    // v[half] + v[half ^ 1] in every lane (halves of 32 lanes)
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // all 64 lanes, result in every lane, no LDS crossbar
+  return swap_add32(swap_add16(sum16(v)));
+}
 // over the 8 lanes sharing lane&7 (stride 8): xor-8 inside a row by row_ror:8, xor-16 / xor-32 by the gfx950
 // row / half swaps (v_permlane16_swap, v_permlane32_swap)
 __device__ __forceinline__ float sum_hi8(float v) {
@@ -108,125 +127,169 @@ __device__ __forceinline__ float sum_hi8(float v) {
   return v;
 }
 
+// theta is never written during a launch: reading it through the constant address space lets the compiler use
+// scalar loads (SGPR operands) wherever the index is wave-uniform.
+typedef const float __attribute__((address_space(4))) cfloat;
+
 template <class Sh>
 struct Lds {
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-  static constexpr int MB = (Sh::M % 4 == 0) ? 4 : Sh::M;          // outputs handled per spec_a-gradient unit
-  static constexpr int Q = Sh::C / 4;                              // 16-byte band chunks per pixel
-  static constexpr int UNITS = Q * (Sh::M / MB);
-  static constexpr int NSL = (Sh::NT / UNITS) < 32 ? (Sh::NT / UNITS) : 32;  // pixel slices of the spec_a gradient
+  static constexpr int QG = Sh::Cg / 4;                            // 16-byte band chunks per spectral group
+  static constexpr int NSLW = (64 / QG) < 16 ? (64 / QG) : 16;     // pixel slices of a wave's spec_a gradient
+  // partial sums of that gradient: a wave whose group is its own (M == 4) recycles its private band slice of the X
+  // tile; groups shared by several waves (M > 4) get a dedicated region
+  static constexpr bool OWN_SLICE = (Sh::M == 4);
+  static constexpr int GSCR = OWN_SLICE ? 0 : Sh::NB * NSLW * 4 * Sh::Cg;
+  static constexpr int RS = (Sh::P + 3) & ~3;                      // row stride of the channel-major maps (floats)
+  static constexpr int FSZ = Sh::P * RS;                           // one channel image
   static constexpr int AUXP = (Sh::PB * Sh::C2 + 3) & ~3;
-  static constexpr int P2P = (Sh::P2 + 3) & ~3;
   static constexpr int NWH = (Sh::H * 8 + 63) / 64;                // waves taking part in the head
-  static constexpr int WA = Sh::F * Sh::Cg + Sh::F;                // staged spec_a weight + bias
   static constexpr int MS = Sh::P;                                 // row-mask stride per channel
-  static constexpr int REST = 2 * Sh::P2 * Sh::Fs + AUXP + P2P + 2 * Sh::F * MS + 2 * Sh::F2 + 2 * Sh::H + 2 * KMAX +
-                              NWH * cmax(Sh::F2, Sh::H) + ((WA + 3) & ~3);
+  static constexpr int DWW = 2 * Sh::F * 12;                       // staged depthwise taps + bias: [branch][F][12]
+  static constexpr int REST = 2 * Sh::F * FSZ + AUXP + Sh::P * RS + 2 * Sh::F * MS + Sh::F2 + 2 * Sh::H + 2 * KMAX +
+                              NWH * cmax(Sh::F2, Sh::H) + GSCR + DWW;
   // X-tile row stride (floats).  (Cs/4) odd makes a 16-lane ds_read_b128 group with lane<->pixel hit 64 distinct
   // banks (MI355X_MICROARCH.md §LDS); the pad is dropped (2-way conflict) only where it would not fit in 160 KiB.
   static constexpr int CsPad = Sh::C + ((((Sh::C / 4) & 1) == 0) ? 4 : 0);
-  static constexpr int Cs = (cmax(Sh::P2 * CsPad, NSL * Sh::F * Sh::Cg) + REST <= 40960) ? CsPad : Sh::C;
-  static constexpr int SCR = cmax(Sh::P2 * Cs, NSL * Sh::F * Sh::Cg);        // X tile, later its gradient partials
+  static constexpr int Cs = (Sh::P2 * CsPad + REST <= 40960) ? CsPad : Sh::C;
+  static constexpr int SCR = Sh::P2 * Cs;                                    // X tile
+  static_assert(!OWN_SLICE || NSLW * 4 <= Sh::P2, "own-slice scratch needs NSLW*4 pixel rows");
   // offsets in floats
   static constexpr int oX = 0;
-  static constexpr int oWa = oX + SCR;                             // [F][Cg] spec_a.weight, then [F] spec_a.bias
-  static constexpr int oY1a = oWa + ((WA + 3) & ~3);
-  static constexpr int oY1b = oY1a + Sh::P2 * Sh::Fs;
-  static constexpr int oAux = oY1b + Sh::P2 * Sh::Fs;
-  static constexpr int oPool = oAux + AUXP;
-  static constexpr int oMaskA = oPool + P2P;
+  static constexpr int oY1a = oX + SCR;                            // [F][P][RS]  spec_a output, later dY1a
+  static constexpr int oY1b = oY1a + Sh::F * FSZ;
+  static constexpr int oAux = oY1b + Sh::F * FSZ;
+  static constexpr int oPool = oAux + AUXP;                        // [P][RS]
+  static constexpr int oMaskA = oPool + Sh::P * RS;
   static constexpr int oMaskB = oMaskA + Sh::F * MS;
   static constexpr int oZ = oMaskB + Sh::F * MS;
   static constexpr int oH = oZ + Sh::F2;
   static constexpr int oDh = oH + Sh::H;
-  static constexpr int oDz = oDh + Sh::H;
-  static constexpr int oLg = oDz + Sh::F2;
+  static constexpr int oLg = oDh + Sh::H;
   static constexpr int oDl = oLg + KMAX;
   static constexpr int oTmp = oDl + KMAX;                          // [NWH][max(2F, H)] ordered partial sums
-  static constexpr int TOTAL = oTmp + NWH * cmax(Sh::F2, Sh::H);
+  static constexpr int TMPW = cmax(Sh::F2, Sh::H);
+  static constexpr int oGscr = oTmp + NWH * TMPW;
+  static constexpr int oDww = oGscr + GSCR;
+  static constexpr int oW2 = oDww + DWW;                           // staged fc2.weight rows [W2ROWS][H] + bias [KMAX]
+  static constexpr int W2ROWS_ = (40960 - (oW2 + KMAX)) / Sh::H;
+  static constexpr int W2ROWS = W2ROWS_ > KMAX ? KMAX : (W2ROWS_ < 0 ? 0 : W2ROWS_);
+  static constexpr int TOTAL = oW2 + KMAX + W2ROWS * Sh::H;
+  // LDS-DMA gather of the window: 256-float (1 KiB) pieces of the padded LDS image, NXW pieces per wave
+  static constexpr int NCH = (SCR + 255) / 256;
+  static constexpr int NXW = (NCH + Sh::NW - 1) / Sh::NW;
+  static constexpr int NAUXI = (Sh::PB * Sh::C2 + 63) / 64;
   static constexpr int BYTES = TOTAL * 4;
-  static_assert(TOTAL == SCR + REST, "LDS carve");
+  static_assert(oW2 == SCR + REST, "LDS carve");
   static_assert(BYTES <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
+  static_assert(SCR % 4 == 0 && FSZ % 4 == 0 && AUXP % 4 == 0, "16-byte aligned regions");
 };
 
 // ---------------------------------------------------------------------------------------- P0 loaders
-// All loads of a thread are issued before the first LDS store, so the whole window is in flight at once.
+// The window gather runs asynchronously (LDS-DMA), so that work which does not need the window — the whole
+// aux-branch forward — runs under its latency.
+// LDS-DMA form of the gather (mode 1): `global_load_lds_dwordx4` writes LDS directly — no staging registers and no
+// ds_write pass, and the wave is free to compute while its pieces are in flight.  The LDS image is lane-linear per
+// piece (wave-uniform base + 16 B x lane), so the piece's lanes are pointed at the SOURCE pixels / bands that belong
+// at their LDS position; lanes that fall on row padding read a harmless in-range address.  Every wave issues exactly
+// NXW pieces (a wave with fewer distinct pieces repeats its last one: same bytes) so that one counted
+// `s_waitcnt vmcnt(NXW)` tells a wave that the loads it issued BEFORE the window (its aux tile) have landed.
 template <class Sh>
-__device__ __forceinline__ void load_x_tile(const dmf_input& in, int b, float* __restrict__ sX, int tid) {
-  if (in.mode == 1) {
-    const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
-    constexpr int Q = Sh::C / 4;
-    constexpr int NQ = Sh::P2 * Q;
-    constexpr int NIT = (NQ + Sh::NT - 1) / Sh::NT;
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(in.sceneA);
-    float4 v[NIT];
-    int dst[NIT];
+__device__ __forceinline__ void x_gather_dma(const dmf_input& in, int b, float* sX, int wave, int lane) {
+  using L = Lds<Sh>;
+  const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
+  const float* __restrict__ base = in.sceneA + ((size_t)x * in.Wp + y) * Sh::C;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int q = i * Sh::NT + tid;
-      const int qc = q < NQ ? q : NQ - 1;
-      const int pix = qc / Q, cc = qc - pix * Q;
-      const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
-      const size_t pixel = (size_t)(x + pr) * in.Wp + (y + pc);
-      v[i] = src[pixel * Q + cc];
-      dst[i] = q < NQ ? pix * Lds<Sh>::Cs + 4 * cc : -1;
+  for (int i = 0; i < L::NXW; ++i) {
+    int k = wave + i * Sh::NW;
+    k = k < L::NCH ? k : L::NCH - 1;
+    const int o = k * 256 + 4 * lane;                       // float offset inside the LDS image
+    const int pix = o / L::Cs, within = o - pix * L::Cs;
+    const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
+    const bool data = o < L::SCR && within < Sh::C;
+    const float* src = base + (data ? (unsigned)((pr * in.Wp + pc) * Sh::C + within) : 0u);
+    if (o < L::SCR)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sX + k * 256), 16, 0, 0);
+  }
+}
+
+template <class Sh>
+__device__ __forceinline__ void aux_gather_dma(const dmf_input& in, int b, float* sAux, int lane) {
+  using L = Lds<Sh>;
+  constexpr int ROW = Sh::SP * Sh::C2, NE = Sh::PB * Sh::C2;
+  const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
+  const float* __restrict__ base = in.sceneB + ((size_t)(Sh::S * x) * in.WpB + (size_t)Sh::S * y) * Sh::C2;
+#pragma unroll
+  for (int i = 0; i < L::NAUXI; ++i) {
+    const int e = i * 64 + lane;
+    const int ec = e < NE ? e : NE - 1;
+    const int r = ec / ROW, rem = ec - r * ROW;
+    const float* src = base + (unsigned)(r * in.WpB * Sh::C2 + rem);
+    if (e < NE)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sAux + i * 64), 4, 0, 0);
+  }
+}
+
+// materialised band-major patches (the reference dataloader's tensors): transposed on the way into LDS
+template <class Sh>
+__device__ __forceinline__ void x_load_patches(const dmf_input& in, int b, float* __restrict__ sX, int tid) {
+  constexpr int Cs = Lds<Sh>::Cs;
+  const float* __restrict__ src = in.a + (size_t)b * Sh::C * Sh::P2;
+  constexpr int NE = Sh::C * Sh::P2;
+  constexpr int UN = 8;
+  for (int e0 = 0; e0 < NE; e0 += UN * Sh::NT) {
+    float v[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const int e = e0 + i * Sh::NT + tid;
+      v[i] = src[e < NE ? e : NE - 1];
     }
 #pragma unroll
-    for (int i = 0; i < NIT; ++i)
-      if (dst[i] >= 0) *reinterpret_cast<float4*>(sX + dst[i]) = v[i];
-  } else {
-    const float* __restrict__ src = in.a + (size_t)b * Sh::C * Sh::P2;
-    constexpr int NE = Sh::C * Sh::P2;
-    constexpr int UN = 8;
-    for (int e0 = 0; e0 < NE; e0 += UN * Sh::NT) {
-      float v[UN];
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int e = e0 + i * Sh::NT + tid;
-        v[i] = src[e < NE ? e : NE - 1];
-      }
-#pragma unroll
-      for (int i = 0; i < UN; ++i) {
-        const int e = e0 + i * Sh::NT + tid;
-        if (e < NE) {
-          const int c = e / Sh::P2, pix = e - c * Sh::P2;
-          sX[pix * Lds<Sh>::Cs + c] = v[i];
-        }
+    for (int i = 0; i < UN; ++i) {
+      const int e = e0 + i * Sh::NT + tid;
+      if (e < NE) {
+        const int c = e / Sh::P2, pix = e - c * Sh::P2;
+        sX[pix * Cs + c] = v[i];
       }
     }
   }
 }
 
-template <class Sh>
-__device__ __forceinline__ void load_aux_tile(const dmf_input& in, int b, float* __restrict__ sAux, int tid) {
+// aux tile -> LDS as [aux pixel][C2].  `nthr` threads starting at `t` cooperate (a whole workgroup, or one wavefront
+// when every wave keeps its own copy of a small tile so that no workgroup barrier is needed before lift_b).
+template <class Sh, int NTHR>
+__device__ __forceinline__ void load_aux_tile(const dmf_input& in, int b, float* __restrict__ sAux, int t) {
   constexpr int ROW = Sh::SP * Sh::C2;
   constexpr int NE = Sh::PB * Sh::C2;
-  constexpr int NIT = (NE + Sh::NT - 1) / Sh::NT;
+  constexpr int NIT = (NE + NTHR - 1) / NTHR;
   float v[NIT];
   if (in.mode == 1) {
     const int x = in.xy[2 * (size_t)b], y = in.xy[2 * (size_t)b + 1];
+    const float* __restrict__ src = in.sceneB + ((size_t)(Sh::S * x) * in.WpB + (size_t)Sh::S * y) * Sh::C2;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = i * Sh::NT + tid;
+      const int e = i * NTHR + t;
       const int ec = e < NE ? e : NE - 1;
       const int r = ec / ROW, rem = ec - r * ROW;
-      v[i] = in.sceneB[((size_t)(Sh::S * x + r) * in.WpB + (size_t)Sh::S * y) * Sh::C2 + rem];
+      v[i] = src[(unsigned)(r * in.WpB * Sh::C2 + rem)];
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = i * Sh::NT + tid;
+      const int e = i * NTHR + t;
       if (e < NE) sAux[e] = v[i];
     }
   } else {
     const float* __restrict__ src = in.b + (size_t)b * Sh::C2 * Sh::PB;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = i * Sh::NT + tid;
+      const int e = i * NTHR + t;
       v[i] = src[e < NE ? e : NE - 1];
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-      const int e = i * Sh::NT + tid;
+      const int e = i * NTHR + t;
       if (e < NE) {
         const int k = e / Sh::PB, pixb = e - k * Sh::PB;
         sAux[pixb * Sh::C2 + k] = v[i];
@@ -235,182 +298,129 @@ __device__ __forceinline__ void load_aux_tile(const dmf_input& in, int b, float*
   }
 }
 
-// ---------------------------------------------------------------------------------------- P2 / P4 row walkers
+// ---------------------------------------------------------------------------------------- spatial stages
+// A thread owns row r of channel f.  Rows r-1, r, r+1 of the channel image are fetched as whole 16-byte-aligned rows;
+// a row index outside the patch is clamped and its contribution is switched off through a 0/1 factor, so there is
+// no per-element bounds logic.
 template <class Sh>
-__device__ __forceinline__ void load_col(const float* sY1, int f, int r, int c, float col[3]) {
+__device__ __forceinline__ void load_row(const float* base, float row[Lds<Sh>::RS]) {
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int rr = r + u - 1;
-    col[u] = (rr >= 0 && rr < Sh::P) ? sY1[(rr * Sh::P + c) * Sh::Fs + f] : 0.f;
+  for (int k = 0; k < Lds<Sh>::RS / 4; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(base + 4 * k);
+    row[4 * k + 0] = v.x; row[4 * k + 1] = v.y; row[4 * k + 2] = v.z; row[4 * k + 3] = v.w;
   }
 }
 
-// The row walkers slide the 3x3 windows of BOTH branches along one patch row in registers.  Column iteration c
-// first issues the LDS loads of column c+2, then computes column c from registers; the sched_barrier keeps the
-// compiler from hoisting every load of the unrolled row to its top (which spills), so the software pipeline is
-// two columns deep and the two branches give each other instruction-level parallelism.
 template <class Sh>
-__device__ __forceinline__ float conv9(const float w[9], const float l[3], const float m[3], const float r[3], float y) {
+__device__ __forceinline__ void load_dww(const float* base, float w[12]) {
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    y = fmaf(w[u * 3 + 0], l[u], y);
-    y = fmaf(w[u * 3 + 1], m[u], y);
-    y = fmaf(w[u * 3 + 2], r[u], y);
+  for (int k = 0; k < 3; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(base + 4 * k);
+    w[4 * k + 0] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
   }
-  return y;
 }
 
-// forward: depthwise 3x3 (zero pad 1) + ReLU of spat_a and spat_b on row r of channel f; ReLU mask words and
-// the pooled partial sums of the row
+// forward of one branch: y = bias + depthwise 3x3 (zero pad 1); ReLU mask word; pooled partial sum of the row
 template <class Sh>
-__device__ __forceinline__ void row_fwd2(const float* sYa, const float* sYb, const float* sPool, int f, int r,
-                                         const float wA[9], float bA, const float wB[9], float bB,
-                                         uint32_t& mkA, float& za, uint32_t& mkB, float& zb) {
-  float a0[3] = {0.f, 0.f, 0.f}, a1[3], a2[3] = {0.f, 0.f, 0.f}, an[3];
-  float b0[3] = {0.f, 0.f, 0.f}, b1[3], b2[3] = {0.f, 0.f, 0.f}, bn[3];
-  load_col<Sh>(sYa, f, r, 0, a1);
-  load_col<Sh>(sYb, f, r, 0, b1);
-  if (Sh::P > 1) { load_col<Sh>(sYa, f, r, 1, a2); load_col<Sh>(sYb, f, r, 1, b2); }
-  float pw = sPool[r * Sh::P], pn = 0.f;
-  mkA = mkB = 0u;
-  za = zb = 0.f;
+__device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>::RS], int f, int r, const float w[9],
+                                        float bias, uint32_t& mask, float& z) {
+  using L = Lds<Sh>;
+  const float m0 = r > 0 ? 1.f : 0.f, m2 = r < Sh::P - 1 ? 1.f : 0.f;
+  const int r0 = r > 0 ? r - 1 : 0, r2 = r < Sh::P - 1 ? r + 1 : Sh::P - 1;
+  float ya[3][L::RS];
+  load_row<Sh>(sY + f * L::FSZ + r0 * L::RS, ya[0]);
+  load_row<Sh>(sY + f * L::FSZ + r * L::RS, ya[1]);
+  load_row<Sh>(sY + f * L::FSZ + r2 * L::RS, ya[2]);
+  float we[9];
+#pragma unroll
+  for (int v = 0; v < 3; ++v) { we[v] = w[v] * m0; we[3 + v] = w[3 + v]; we[6 + v] = w[6 + v] * m2; }
+  mask = 0u;
+  z = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    if (c + 2 < Sh::P) { load_col<Sh>(sYa, f, r, c + 2, an); load_col<Sh>(sYb, f, r, c + 2, bn); }
-    else { an[0] = an[1] = an[2] = 0.f; bn[0] = bn[1] = bn[2] = 0.f; }
-    if (c + 1 < Sh::P) pn = sPool[r * Sh::P + c + 1];
-    const float ya = conv9<Sh>(wA, a0, a1, a2, bA);
-    const float yb = conv9<Sh>(wB, b0, b1, b2, bB);
-    if (ya > 0.f) { mkA |= (1u << c); za = fmaf(pw, ya, za); }
-    if (yb > 0.f) { mkB |= (1u << c); zb = fmaf(pw, yb, zb); }
+    float y = bias;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; a2[u] = an[u]; b0[u] = b1[u]; b1[u] = b2[u]; b2[u] = bn[u]; }
-    pw = pn;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// backward, pass 1 (before the barrier): weight / bias gradient partials of this row, both branches.
-//   dY2(r,c)  = mask(r,c) ? dz[f] * pool[r,c] : 0
-//   dW[u][v] += dY2(r,c) * Y1(r+u-1, c+v-1),  db += dY2(r,c)
-template <class Sh>
-__device__ __forceinline__ void row_bwd_w2(const float* sYa, const float* sYb, const uint32_t* sMkA, const uint32_t* sMkB,
-                                           const float* sPool, int f, int r, float dza, float dzb,
-                                           float dwa[9], float& dba, float dwb[9], float& dbb) {
-  const uint32_t ma = sMkA[f * Lds<Sh>::MS + r], mb = sMkB[f * Lds<Sh>::MS + r];
-  float a0[3] = {0.f, 0.f, 0.f}, a1[3], a2[3] = {0.f, 0.f, 0.f}, an[3];
-  float b0[3] = {0.f, 0.f, 0.f}, b1[3], b2[3] = {0.f, 0.f, 0.f}, bn[3];
-  load_col<Sh>(sYa, f, r, 0, a1);
-  load_col<Sh>(sYb, f, r, 0, b1);
-  if (Sh::P > 1) { load_col<Sh>(sYa, f, r, 1, a2); load_col<Sh>(sYb, f, r, 1, b2); }
-  float pw = sPool[r * Sh::P], pn = 0.f;
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { dwa[k] = 0.f; dwb[k] = 0.f; }
-  dba = dbb = 0.f;
-#pragma unroll
-  for (int c = 0; c < Sh::P; ++c) {
-    if (c + 2 < Sh::P) { load_col<Sh>(sYa, f, r, c + 2, an); load_col<Sh>(sYb, f, r, c + 2, bn); }
-    else { an[0] = an[1] = an[2] = 0.f; bn[0] = bn[1] = bn[2] = 0.f; }
-    if (c + 1 < Sh::P) pn = sPool[r * Sh::P + c + 1];
-    const float da = ((ma >> c) & 1u) ? dza * pw : 0.f;
-    const float db = ((mb >> c) & 1u) ? dzb * pw : 0.f;
-    dba += da;
-    dbb += db;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      dwa[u * 3 + 0] = fmaf(da, a0[u], dwa[u * 3 + 0]);
-      dwa[u * 3 + 1] = fmaf(da, a1[u], dwa[u * 3 + 1]);
-      dwa[u * 3 + 2] = fmaf(da, a2[u], dwa[u * 3 + 2]);
-      dwb[u * 3 + 0] = fmaf(db, b0[u], dwb[u * 3 + 0]);
-      dwb[u * 3 + 1] = fmaf(db, b1[u], dwb[u * 3 + 1]);
-      dwb[u * 3 + 2] = fmaf(db, b2[u], dwb[u * 3 + 2]);
+      for (int v = 0; v < 3; ++v) {
+        const int cc = c + v - 1;
+        if (cc >= 0 && cc < Sh::P) y = fmaf(we[u * 3 + v], ya[u][cc], y);
+      }
+    if (y > 0.f) {
+      mask |= (1u << c);
+      z = fmaf(pw[c], y, z);
     }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; a2[u] = an[u]; b0[u] = b1[u]; b1[u] = b2[u]; b2[u] = bn[u]; }
-    pw = pn;
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// backward, pass 2 (after the barrier: no thread reads a neighbour's Y1 any more): dY1 of this row, in place, for
-// both branches, plus this row's share of the bias gradients of spec_a / lift_b and of the lift_b weight gradient.
-//   dY1(r,c) = (Y1(r,c) > 0) * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1)
-//   d lift_b.weight[f][k][u][v] += dY1b(r,c) * aux[k][S r + u][S c + v]
+// backward pass 1 of one branch: dW[u][v] += dY2(r,c) * Y1(r+u-1, c+v-1), db += dY2(r,c),
+// with dY2(r,c) = mask(r,c) ? dz * pool[r,c] : 0
 template <class Sh>
-__device__ __forceinline__ void row_bwd_x2(float* sYa, float* sYb, const uint32_t* sMkA, const uint32_t* sMkB,
-                                           const float* sPool, const float* sAux, int f, int r,
-                                           const float wA[9], const float wB[9], float dza, float dzb,
-                                           float& dbias_a, float& dbias_b, float dwl[Sh::TB]) {
-  uint32_t ma[3], mb[3];
-  int rc[3];
+__device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh>::RS], uint32_t mr, int f, int r, float dz,
+                                          float dw[9], float& db) {
+  using L = Lds<Sh>;
+  const float m0 = r > 0 ? 1.f : 0.f, m2 = r < Sh::P - 1 ? 1.f : 0.f;
+  const int r0 = r > 0 ? r - 1 : 0, r2 = r < Sh::P - 1 ? r + 1 : Sh::P - 1;
+  float ya[3][L::RS];
+  load_row<Sh>(sY + f * L::FSZ + r0 * L::RS, ya[0]);
+  load_row<Sh>(sY + f * L::FSZ + r * L::RS, ya[1]);
+  load_row<Sh>(sY + f * L::FSZ + r2 * L::RS, ya[2]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dw[k] = 0.f;
+  db = 0.f;
+#pragma unroll
+  for (int c = 0; c < Sh::P; ++c) {
+    const float d2 = ((mr >> c) & 1u) ? dz * pw[c] : 0.f;
+    db += d2;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int cc = c + v - 1;
+        if (cc >= 0 && cc < Sh::P) dw[u * 3 + v] = fmaf(d2, ya[u][cc], dw[u * 3 + v]);
+      }
+  }
+#pragma unroll
+  for (int v = 0; v < 3; ++v) { dw[v] *= m0; dw[6 + v] *= m2; }
+}
+
+// backward pass 2 of one branch (after the barrier: nobody reads a neighbour's Y1 any more): dY1 of this row, in
+// place.   dY1(r,c) = (Y1(r,c) > 0) * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1);  returns the row in dy[] as well
+template <class Sh>
+__device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const uint32_t* sMk, int f, int r,
+                                          const float w[9], float dz, float dy[Lds<Sh>::RS]) {
+  using L = Lds<Sh>;
+  float g[3][L::RS];       // g[u][c] = dY2 at (r+u-1, c); zero outside the patch
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
     const int rr = r + u - 1;
     const bool in = rr >= 0 && rr < Sh::P;
-    ma[u] = in ? sMkA[f * Lds<Sh>::MS + rr] : 0u;     // the masks are 0 outside the patch
-    mb[u] = in ? sMkB[f * Lds<Sh>::MS + rr] : 0u;
-    rc[u] = in ? rr : r;
-  }
-  // g*[col][u] = dY2 at (r+u-1, col); three columns live: c-1, c, c+1
-  float ga0[3] = {0.f, 0.f, 0.f}, ga1[3], ga2[3], gb0[3] = {0.f, 0.f, 0.f}, gb1[3], gb2[3];
-  float pn[3];
+    const uint32_t mm = in ? sMk[f * L::MS + rr] : 0u;
+    float pw[L::RS];
+    load_row<Sh>(sPool + (in ? rr : r) * L::RS, pw);
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const float pw = sPool[rc[u] * Sh::P];
-    ga1[u] = (ma[u] & 1u) ? dza * pw : 0.f;
-    gb1[u] = (mb[u] & 1u) ? dzb * pw : 0.f;
-    pn[u] = (Sh::P > 1) ? sPool[rc[u] * Sh::P + 1] : 0.f;
+    for (int c = 0; c < Sh::P; ++c) g[u][c] = ((mm >> c) & 1u) ? dz * pw[c] : 0.f;
   }
-  float ya = sYa[(r * Sh::P) * Sh::Fs + f], yb = sYb[(r * Sh::P) * Sh::Fs + f];
-  dbias_a = dbias_b = 0.f;
+  float y1[L::RS];
+  float* row = sY + f * L::FSZ + r * L::RS;
+  load_row<Sh>(row, y1);
 #pragma unroll
-  for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
+  for (int c = 0; c < L::RS; ++c) dy[c] = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    // column c+1 of dY2 from the pool values fetched one iteration ago; fetch column c+2's pool and column c+1's Y1
+    float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      ga2[u] = (c + 1 < Sh::P && ((ma[u] >> (c + 1)) & 1u)) ? dza * pn[u] : 0.f;
-      gb2[u] = (c + 1 < Sh::P && ((mb[u] >> (c + 1)) & 1u)) ? dzb * pn[u] : 0.f;
-    }
-    if (c + 2 < Sh::P) {
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int u = 0; u < 3; ++u) pn[u] = sPool[rc[u] * Sh::P + c + 2];
-    }
-    float yan = 0.f, ybn = 0.f;
-    if (c + 1 < Sh::P) { yan = sYa[(r * Sh::P + c + 1) * Sh::Fs + f]; ybn = sYb[(r * Sh::P + c + 1) * Sh::Fs + f]; }
-    float ax[Sh::TB];
-#pragma unroll
-    for (int k = 0; k < Sh::C2; ++k)
-#pragma unroll
-      for (int u = 0; u < Sh::S; ++u)
-#pragma unroll
-        for (int v = 0; v < Sh::S; ++v)
-          ax[(k * Sh::S + u) * Sh::S + v] = sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k];
-    float sa = 0.f, sb = 0.f;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {   // W[u][v] pairs with dY2(r-u+1, c-v+1) = G[2-u][2-v]
-      sa = fmaf(wA[u * 3 + 0], ga2[2 - u], sa);
-      sa = fmaf(wA[u * 3 + 1], ga1[2 - u], sa);
-      sa = fmaf(wA[u * 3 + 2], ga0[2 - u], sa);
-      sb = fmaf(wB[u * 3 + 0], gb2[2 - u], sb);
-      sb = fmaf(wB[u * 3 + 1], gb1[2 - u], sb);
-      sb = fmaf(wB[u * 3 + 2], gb0[2 - u], sb);
-    }
-    const float da = (ya > 0.f) ? sa : 0.f;
-    const float db = (yb > 0.f) ? sb : 0.f;
-    sYa[(r * Sh::P + c) * Sh::Fs + f] = da;
-    sYb[(r * Sh::P + c) * Sh::Fs + f] = db;
-    dbias_a += da;
-    dbias_b += db;
-#pragma unroll
-    for (int q = 0; q < Sh::TB; ++q) dwl[q] = fmaf(db, ax[q], dwl[q]);
-#pragma unroll
-    for (int u = 0; u < 3; ++u) { ga0[u] = ga1[u]; ga1[u] = ga2[u]; gb0[u] = gb1[u]; gb1[u] = gb2[u]; }
-    ya = yan;
-    yb = ybn;
-    __builtin_amdgcn_sched_barrier(0);
+      for (int v = 0; v < 3; ++v) {   // W[u][v] pairs with dY2(r-u+1, c-v+1) = g[2-u][c-v+1]
+        const int cc = c - v + 1;
+        if (cc >= 0 && cc < Sh::P) s = fmaf(w[u * 3 + v], g[2 - u][cc], s);
+      }
+    dy[c] = (y1[c] > 0.f) ? s : 0.f;
   }
+#pragma unroll
+  for (int k = 0; k < L::RS / 4; ++k)
+    *reinterpret_cast<float4*>(row + 4 * k) = make_float4(dy[4 * k], dy[4 * k + 1], dy[4 * k + 2], dy[4 * k + 3]);
 }
 
 // ---------------------------------------------------------------------------------------- the kernel
@@ -419,149 +429,210 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   using L = Lds<Sh>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sX = smem + L::oX;
-  float* sWa = smem + L::oWa;
   float* sY1a = smem + L::oY1a;
   float* sY1b = smem + L::oY1b;
   float* sAux = smem + L::oAux;
   float* sPool = smem + L::oPool;
-  uint32_t* sMaskA = reinterpret_cast<uint32_t*>(smem + L::oMaskA);   // [F][16] row masks of spat_a's ReLU
+  uint32_t* sMaskA = reinterpret_cast<uint32_t*>(smem + L::oMaskA);   // [F][P] row masks of spat_a's ReLU
   uint32_t* sMaskB = reinterpret_cast<uint32_t*>(smem + L::oMaskB);
   float* sZ = smem + L::oZ;
   float* sH = smem + L::oH;
   float* sDh = smem + L::oDh;
-  float* sDz = smem + L::oDz;
   float* sLg = smem + L::oLg;
   float* sDl = smem + L::oDl;
   float* sTmp = smem + L::oTmp;
-  constexpr int TMPW = L::cmax(Sh::F2, Sh::H);
+  float* sGscr = smem + L::oGscr;
+  constexpr int TMPW = L::TMPW;
 
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const float* __restrict__ th = a.theta;
+  cfloat* thc = (cfloat*)a.theta;
   const int K = a.K;
   const int B = a.in.B;
   float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB;
 
-  for (int i = tid0; i < Sh::P2; i += Sh::NT) sPool[i] = a.pool[i];
-  // spec_a weights + bias -> LDS once per workgroup (read back as wave-uniform broadcasts in P1; the compiler
-  // cannot prove theta read-only, so it would otherwise fetch them through per-lane vector loads)
-  for (int i = tid0; i < L::WA; i += Sh::NT) sWa[i] = th[Sh::oA1w + i];
+  for (int i = tid0; i < Sh::P * L::RS; i += Sh::NT) {   // pooling profile, rows padded to RS
+    const int r = i / L::RS, c = i - r * L::RS;
+    sPool[i] = c < Sh::P ? a.pool[r * Sh::P + c] : 0.f;
+  }
+  float* sDww = smem + L::oDww;
+  for (int i = tid0; i < 2 * Sh::F * 12; i += Sh::NT) {   // depthwise taps + bias of both branches: [branch][F][12]
+    const int br = i / (Sh::F * 12), rem = i - br * (Sh::F * 12);
+    const int f = rem / 12, k = rem - f * 12;
+    float v = 0.f;
+    if (k < 9) v = th[(unsigned)((br ? Sh::oB2w : Sh::oA2w) + f * 9 + k)];
+    else if (k == 9) v = th[(unsigned)((br ? Sh::oB2b : Sh::oA2b) + f)];
+    sDww[i] = v;
+  }
+  float* sB2 = smem + L::oW2;                 // fc2.bias [KMAX]
+  float* sW2 = sB2 + KMAX;                    // fc2.weight rows 0..min(K, W2ROWS)-1, [row][H]
+  const int kst = K < L::W2ROWS ? K : L::W2ROWS;
+  for (int i = tid0; i < kst * Sh::H; i += Sh::NT) sW2[i] = th[(unsigned)(Sh::oFc2w + i)];
+  for (int i = tid0; i < KMAX; i += Sh::NT) sB2[i] = i < K ? th[(unsigned)(Sh::oFc2w + K * Sh::H + i)] : 0.f;
   if (MODE == MODE_TRAIN && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? a.in.cursor[0] * B : 0;   // epoch-plan offset of this batch
+  __syncthreads();
 
-  constexpr int N1 = (Sh::F2 + 7) / 8, N2 = (Sh::H + 7) / 8;
-  constexpr int NPL = Sh::NT / Sh::F;
+  constexpr int N1 = (Sh::F2 + 7) / 8;
+  constexpr int NPH = (Sh::P2 + 63) / 64;
+  constexpr bool AUX_WAVE = (Sh::PB * Sh::C2 <= 256);        // small aux tile: every wave loads its own copy
+  static_assert(Sh::H == 64, "the single-wave fc2 / softmax / dh step maps lane <-> hidden unit");
 
   bool first = true;
   for (int b = blockIdx.x; b < B; b += gridDim.x, first = false) {
     int tid = tid0;
     OPAQUE(tid);    // roles are re-derived from an opaque copy per patch (and again per backward phase) so their
-                    // address arithmetic lives inside the phase that uses it
-    // spatial stages: thread <-> (channel fS, row rS);  head: thread <-> (row jH of fc1 / fc2, part pH), column
-    // i = pH + 8*m;  lift_b: thread <-> (channel fL, pixel lane pL)
+                    // address arithmetic lives inside the phase that uses it instead of being hoisted and spilled
+    // spatial stages: thread <-> (channel fS, row rS);  fc1: thread <-> (row jH, part pH), column i = pH + 8*m
     int fS = tid >> 4, rS = tid & 15;
     const bool spat = fS < Sh::F;
-    const int fSc = spat ? fS : Sh::F - 1;
+    const unsigned fSc = spat ? fS : Sh::F - 1;
     const int jH = tid >> 3, pH = tid & 7;
-    const int fL = tid % Sh::F, pL = tid / Sh::F;
-    // ------------------------------------------------------------------ P0
+    const int pixl = lane;     // lane <-> pixel of a wave-task's 64-pixel half
+    int label = 0;             // fetched now, needed in the head
+    if (MODE == MODE_TRAIN) {
+      label = a.labels[boff + b];
+      label = label < 0 ? 0 : (label >= K ? K - 1 : label);
+      label = __builtin_amdgcn_readfirstlane(label);
+    }
+    // ------------------------------------------------------------------ P0: issue the window gather
     STAMP(0);
-    load_x_tile<Sh>(a.in, boff + b, sX, tid);
-    load_aux_tile<Sh>(a.in, boff + b, sAux, tid);
-    __syncthreads();
+    if (a.in.mode == 1) {
+      if (AUX_WAVE) {
+        aux_gather_dma<Sh>(a.in, boff + b, sAux, lane);               // every wave fetches its own (identical) copy
+      } else {
+        load_aux_tile<Sh, Sh::NT>(a.in, boff + b, sAux, tid);
+        __syncthreads();
+      }
+      x_gather_dma<Sh>(a.in, boff + b, sX, wave, lane);
+      // this wave's aux pieces were issued before its NXW window pieces: they have landed once at most NXW loads
+      // are outstanding (vmcnt counts in issue order)
+      if (AUX_WAVE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NXW) : "memory");
+    } else {
+      load_aux_tile<Sh, Sh::NT>(a.in, boff + b, sAux, tid);
+      x_load_patches<Sh>(a.in, boff + b, sX, tid);
+      __syncthreads();
+    }
+    float wB[12];
+    load_dww<Sh>(sDww + (Sh::F + fSc) * 12, wB);
+    const float bB = wB[9];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ------------------------------------------------------------------ aux branch forward, under the gather latency
+    // lift_b (SxS stride-S conv + ReLU): wave-task = (block of 4 channels, 64-pixel half), weights in SGPRs
+    for (int task = wave; task < Sh::NB * NPH; task += Sh::NW) {
+      const int fb = task % Sh::NB, ph = task / Sh::NB;
+      const int pix = ph * 64 + pixl;
+      const bool valid = pix < Sh::P2;
+      const int pixc = valid ? pix : Sh::P2 - 1;
+      const int pr = pixc / Sh::P, pc = pixc - pr * Sh::P;
+      float ax[Sh::TB];
+#pragma unroll
+      for (int k = 0; k < Sh::C2; ++k)
+#pragma unroll
+        for (int u = 0; u < Sh::S; ++u)
+#pragma unroll
+          for (int v = 0; v < Sh::S; ++v)
+            ax[(k * Sh::S + u) * Sh::S + v] = sAux[((Sh::S * pr + u) * Sh::SP + (Sh::S * pc + v)) * Sh::C2 + k];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int f = fb * 4 + m;
+        float acc = thc[Sh::oB1b + f];
+#pragma unroll
+        for (int q = 0; q < Sh::TB; ++q) acc = fmaf(thc[Sh::oB1w + f * Sh::TB + q], ax[q], acc);
+        if (valid) sY1b[f * L::FSZ + pr * L::RS + pc] = fmaxf(acc, 0.f);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // spat_b: depthwise 3x3 + ReLU + pooling on the wave's own 4 channels
+    float zb = 0.f;
+    if (spat && rS < Sh::P) {
+      float pwrow[L::RS];
+      load_row<Sh>(sPool + rS * L::RS, pwrow);
+      uint32_t mkb;
+      row_fwd<Sh>(sY1b, pwrow, fS, rS, wB, bB, mkb, zb);
+      sMaskB[fS * L::MS + rS] = mkb;
+    }
+    zb = sum16(zb);
+    if (spat && rS == 0) sZ[Sh::F + fS] = zb;
     STAMP(1);
 
-    // per-thread weights for this patch: issued here, first used in P2 / P3, so their L2 latency hides under P1
-    float wA[9], wB[9];
+    // ------------------------------------------------------------------ the window must have landed (the compiler
+    // drains vmcnt before the barrier; every wave has issued all its pieces above)
+    __syncthreads();
+    float wA[12];
+    load_dww<Sh>(sDww + fSc * 12, wA);
+    const float bA = wA[9];
+    STAMP(2);
+
+    // ------------------------------------------------------------------ P1: spec_a (grouped 1x1) + ReLU
+    // wave-task = (block of 4 channels, 64-pixel half); the block's group supplies the bands; weights in SGPRs
+    for (int task = wave; task < Sh::NB * NPH; task += Sh::NW) {
+      const int blk = task % Sh::NB, ph = task / Sh::NB;
+      const int g = (4 * blk) / Sh::M, mo = 4 * blk - g * Sh::M;     // group and first output inside it
+      const int pix = ph * 64 + pixl;
+      const bool valid = pix < Sh::P2;
+      const int pixc = valid ? pix : Sh::P2 - 1;
+      const int pr = pixc / Sh::P, pc = pixc - pr * Sh::P;
+      cfloat* wg = thc + Sh::oA1w + (g * Sh::M + mo) * Sh::Cg;       // wave-uniform -> SGPRs
+      float acc[4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { wA[k] = th[Sh::oA2w + fSc * 9 + k]; wB[k] = th[Sh::oB2w + fSc * 9 + k]; }
-    const float bA = th[Sh::oA2b + fSc], bB = th[Sh::oB2b + fSc];
-    float w1r[N1], w2r[N2];
+      for (int m = 0; m < 4; ++m) acc[m] = thc[Sh::oA1b + g * Sh::M + mo + m];
+      const float* xrow = sX + pixc * L::Cs + g * Sh::Cg;
+#pragma unroll
+      for (int j4 = 0; j4 < Sh::Cg / 4; ++j4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xrow + 4 * j4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 0], xv.x, acc[m]);
+          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 1], xv.y, acc[m]);
+          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 2], xv.z, acc[m]);
+          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 3], xv.w, acc[m]);
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sY1a[(4 * blk + m) * L::FSZ + pr * L::RS + pc] = fmaxf(acc[m], 0.f);
+      }
+    }
+    // head weights: issued here, used after spat_a, so their L2 latency hides under it
+    float w1r[N1];
 #pragma unroll
     for (int m = 0; m < N1; ++m) {
       const int i = pH + 8 * m;
-      w1r[m] = (jH < Sh::H && i < Sh::F2) ? th[Sh::oFc1w + jH * Sh::F2 + i] : 0.f;
+      w1r[m] = (jH < Sh::H && i < Sh::F2) ? th[(unsigned)(Sh::oFc1w + jH * Sh::F2 + i)] : 0.f;
     }
-#pragma unroll
-    for (int m = 0; m < N2; ++m) {
-      const int j = pH + 8 * m;
-      w2r[m] = (jH < K && j < Sh::H) ? th[Sh::oFc2w + jH * Sh::H + j] : 0.f;
-    }
-    const float b1H = (jH < Sh::H) ? th[Sh::oFc1b + jH] : 0.f;
-    const float b2H = (jH < K) ? th[Sh::oFc2w + K * Sh::H + jH] : 0.f;
-    float wL[Sh::TB];
-#pragma unroll
-    for (int q = 0; q < Sh::TB; ++q) wL[q] = th[Sh::oB1w + fL * Sh::TB + q];
-    const float bL = th[Sh::oB1b + fL];
+    const float b1H = (jH < Sh::H) ? th[(unsigned)(Sh::oFc1b + jH)] : 0.f;
+    // From here to the head every wave works on the 4 channels it has just produced (lanes = 4 channels x 16 rows):
+    // no workgroup barrier, only the wave's own LDS ordering.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ------------------------------------------------------------------ P1: spec_a (grouped 1x1) + ReLU, lift_b
+    // ------------------------------------------------------------------ P2: spat_a depthwise 3x3 + ReLU + pooling
     {
-      constexpr int NPH = (Sh::P2 + 63) / 64;
-      for (int task = wave; task < Sh::G * NPH; task += Sh::NW) {
-        const int g = task / NPH, ph = task - g * NPH;
-        const int pix = ph * 64 + lane;
-        const bool valid = pix < Sh::P2;
-        const int pixc = valid ? pix : Sh::P2 - 1;
-        const float* wg = sWa + g * Sh::M * Sh::Cg;
-        float acc[Sh::M];
-#pragma unroll
-        for (int m = 0; m < Sh::M; ++m) acc[m] = sWa[Sh::F * Sh::Cg + g * Sh::M + m];
-        const float* xr = sX + pixc * Lds<Sh>::Cs + g * Sh::Cg;
-#pragma unroll
-        for (int j4 = 0; j4 < Sh::Cg / 4; ++j4) {
-          const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * j4);
-#pragma unroll
-          for (int m = 0; m < Sh::M; ++m) {
-            acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 0], xv.x, acc[m]);
-            acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 1], xv.y, acc[m]);
-            acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 2], xv.z, acc[m]);
-            acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 3], xv.w, acc[m]);
-          }
-        }
-        if (valid) {
-#pragma unroll
-          for (int m = 0; m < Sh::M; ++m) sY1a[pix * Sh::Fs + g * Sh::M + m] = fmaxf(acc[m], 0.f);
-        }
-      }
-      // lift_b (SxS stride-S conv) + ReLU
-      if (pL < NPL) {
-        for (int pix = pL; pix < Sh::P2; pix += NPL) {
-          const int r = pix / Sh::P, c = pix - r * Sh::P;
-          float acc = bL;
-#pragma unroll
-          for (int k = 0; k < Sh::C2; ++k)
-#pragma unroll
-            for (int u = 0; u < Sh::S; ++u)
-#pragma unroll
-              for (int v = 0; v < Sh::S; ++v)
-                acc = fmaf(wL[(k * Sh::S + u) * Sh::S + v],
-                           sAux[((Sh::S * r + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k], acc);
-          sY1b[pix * Sh::Fs + fL] = fmaxf(acc, 0.f);
-        }
-      }
-    }
-    __syncthreads();
-    STAMP(2);
-
-    // ------------------------------------------------------------------ P2: depthwise 3x3 + ReLU + pooling
-    {
-      float za = 0.f, zb = 0.f;
+      float za = 0.f;
       if (spat && rS < Sh::P) {
-        uint32_t mka, mkb;
-        row_fwd2<Sh>(sY1a, sY1b, sPool, fS, rS, wA, bA, wB, bB, mka, za, mkb, zb);
+        uint32_t mka;
+        float pwrow[L::RS];
+        load_row<Sh>(sPool + rS * L::RS, pwrow);
+        row_fwd<Sh>(sY1a, pwrow, fS, rS, wA, bA, mka, za);
         sMaskA[fS * L::MS + rS] = mka;
-        sMaskB[fS * L::MS + rS] = mkb;
       }
       za = sum16(za);
-      zb = sum16(zb);
-      if (spat && rS == 0) { sZ[fS] = za; sZ[Sh::F + fS] = zb; }
+      if (spat && rS == 0) sZ[fS] = za;
     }
-    __syncthreads();
+    LDS_BARRIER();
     STAMP(3);
 
     // ------------------------------------------------------------------ P3: head
-    {
+    {   // fc1 + ReLU, all waves: thread (jH, pH) holds W1[jH][pH + 8m]
       float acc = 0.f;
 #pragma unroll
       for (int m = 0; m < N1; ++m) {
@@ -571,78 +642,75 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       acc = sum8(acc);
       if (jH < Sh::H && pH == 0) sH[jH] = fmaxf(acc + b1H, 0.f);
     }
-    __syncthreads();
-    {
+    LDS_BARRIER();
+    {   // fc2, all waves: thread (k = jH, pH) sums W2[k][pH + 8m] h[pH + 8m]; rows staged in LDS (beyond: from L2)
+      constexpr int N2 = (Sh::H + 7) / 8;
       float acc = 0.f;
+      if (jH < K) {
+        if (jH < kst) {
 #pragma unroll
-      for (int m = 0; m < N2; ++m) {
-        const int j = pH + 8 * m;
-        acc = fmaf(w2r[m], (j < Sh::H) ? sH[j] : 0.f, acc);
+          for (int m = 0; m < N2; ++m) acc = fmaf(sW2[jH * Sh::H + pH + 8 * m], sH[pH + 8 * m], acc);
+        } else {
+#pragma unroll
+          for (int m = 0; m < N2; ++m) acc = fmaf(th[(unsigned)(Sh::oFc2w + jH * Sh::H + pH + 8 * m)], sH[pH + 8 * m], acc);
+        }
       }
       acc = sum8(acc);
-      if (jH < K && pH == 0) sLg[jH] = acc + b2H;
+      if (jH < K && pH == 0) sLg[jH] = acc + sB2[jH];
     }
-    __syncthreads();
-    if (wave == 0) {   // softmax cross-entropy by wavefront shuffles (one wave64 covers K <= 64 logits)
-      const float v = lane < K ? sLg[lane] : -INFINITY;
-      const float mx = wave_max(v);
-      if (MODE != MODE_BWD || a.logits != nullptr) {
-        if (lane < K) a.logits[(size_t)b * K + lane] = v;
+    LDS_BARRIER();
+    float lg = -INFINITY, loss_b = 0.f;     // wave 0: this patch's logit of class `lane`, its CE loss
+    int pred_b = 0;
+    if (wave == 0) {
+      // softmax cross-entropy and dh in ONE wavefront (lane <-> class k, then lane <-> hidden unit j), no barriers
+      lg = lane < K ? sLg[lane] : -INFINITY;
+      const float mx = wave_max(lg);
+      {
+        const unsigned long long bal = __ballot(lg == mx);
+        pred_b = __ffsll((long long)bal) - 1;                      // first maximal index, as torch.max
       }
-      if (a.pred != nullptr) {
-        const unsigned long long bal = __ballot(v == mx);
-        if (lane == 0) a.pred[b] = __ffsll((long long)bal) - 1;   // first maximal index, as torch.max
-      }
-      if (MODE == MODE_TRAIN) {
-        const float e = lane < K ? expf(v - mx) : 0.f;
-        const float s = wave_sum(e);
-        int t = a.labels[boff + b];
-        t = t < 0 ? 0 : (t >= K ? K - 1 : t);
-        if (lane < K) sDl[lane] = (e / s - (lane == t ? 1.f : 0.f)) * a.loss_scale;
-        if (lane == 0) a.loss[b] = (mx + logf(s)) - sLg[t];
-      } else if (MODE == MODE_BWD) {
-        if (lane < K) sDl[lane] = a.dlogits[(size_t)b * K + lane];
+      if (MODE != MODE_FWD) {
+        float dl = 0.f;
+        if (MODE == MODE_TRAIN) {
+          const float e = lane < K ? expf(lg - mx) : 0.f;
+          const float se = wave_sum_dpp(e);
+          dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * a.loss_scale : 0.f;
+          const float lgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lg), label));
+          loss_b = (mx + logf(se)) - lgt;
+        } else {
+          dl = lane < K ? a.dlogits[(size_t)b * K + lane] : 0.f;
+        }
+        sDl[lane] = dl;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // dh[j] = relu'(h[j]) * sum_k W2[k][j] dl[k]
+        float dh = 0.f;
+        if (K <= kst) {
+          for (int k = 0; k < K; ++k) dh = fmaf(sW2[k * Sh::H + lane], sDl[k], dh);
+        } else {
+          for (int k = 0; k < K; ++k) dh = fmaf(th[(unsigned)(Sh::oFc2w + k * Sh::H + lane)], sDl[k], dh);
+        }
+        sDh[lane] = sH[lane] > 0.f ? dh : 0.f;
       }
     }
-    if (MODE == MODE_FWD) {
-      __syncthreads();
-      STAMP(4);
-      continue;
-    }
-    __syncthreads();
+    LDS_BARRIER();
     STAMP(4);
-
-    // head backward with the register-resident rows:
-    //   dh[j] = relu'(h[j]) * sum_k W2[k][j] dl[k]   : thread (k, part) holds W2[k][part + 8m]
-    //   dz[i] =               sum_j W1[j][i] dh[j]   : thread (j, part) holds W1[j][part + 8m]
-    // sum over the 8 rows of a wave by shuffles (lane stride 8), then over waves in fixed order through LDS.
-    {
-      const float dl = (jH < K) ? sDl[jH] : 0.f;
-#pragma unroll
-      for (int m = 0; m < N2; ++m) {
-        const float p = sum_hi8(w2r[m] * dl);
-        const int j = pH + 8 * m;
-        if (wave < L::NWH && (lane >> 3) == 0 && j < Sh::H) sTmp[wave * TMPW + j] = p;
-      }
+    // global results of the head leave after the barrier, off the critical path: wave 0 stores what it holds in
+    // registers, the last wave copies the head vectors the gradient-reduce kernel needs from LDS
+    if (wave == 0) {
+      if ((MODE != MODE_BWD || a.logits != nullptr) && lane < K) a.logits[(size_t)b * K + lane] = lg;
+      if (a.pred != nullptr && lane == 0) a.pred[b] = pred_b;
+      if (MODE == MODE_TRAIN && lane == 0) a.loss[b] = loss_b;
     }
-    __syncthreads();
-    if (tid < Sh::H) {
-      float s = 0.f;
-      const int nwk = (K * 8 + 63) / 64;      // waves that hold rows of fc2
-      for (int w = 0; w < nwk; ++w) s += sTmp[w * TMPW + tid];
-      const float hv = sH[tid];
-      const float dh = hv > 0.f ? s : 0.f;
-      sDh[tid] = dh;
-      a.ws_h[(size_t)b * Sh::H + tid] = hv;
-      a.ws_dh[(size_t)b * Sh::H + tid] = dh;
-    } else if (tid >= 64 && tid < 64 + KMAX) {
-      const int k = tid - 64;
-      a.ws_dl[(size_t)b * KMAX + k] = k < K ? sDl[k] : 0.f;
-    } else if (tid >= 128 && tid < 128 + Sh::F2) {
-      a.ws_z[(size_t)b * Sh::F2 + (tid - 128)] = sZ[tid - 128];
+    if (MODE == MODE_FWD) continue;       // (the next patch's gather is fenced by its own barriers)
+    if (wave == Sh::NW - 1) {
+      a.ws_h[(size_t)b * Sh::H + lane] = sH[lane];
+      a.ws_dh[(size_t)b * Sh::H + lane] = sDh[lane];
+      a.ws_dl[(size_t)b * KMAX + lane] = sDl[lane];
+      for (int i = lane; i < Sh::F2; i += 64) a.ws_z[(size_t)b * Sh::F2 + i] = sZ[i];
     }
-    __syncthreads();
-    {
+    {   // dz[i] = sum_j W1[j][i] dh[j]: 8 rows of a wave by DPP / permlane swaps (lane stride 8), waves in fixed order
       const float dh = (jH < Sh::H) ? sDh[jH] : 0.f;
 #pragma unroll
       for (int m = 0; m < N1; ++m) {
@@ -651,24 +719,25 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         if (wave < L::NWH && (lane >> 3) == 0 && i < Sh::F2) sTmp[wave * TMPW + i] = p;
       }
     }
-    __syncthreads();
-    if (tid < Sh::F2) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < L::NWH; ++w) s += sTmp[w * TMPW + tid];
-      sDz[tid] = s;
-    }
-    __syncthreads();
+    LDS_BARRIER();
     STAMP(5);
 
     // ------------------------------------------------------------------ P4: depthwise backward
     OPAQUE(tid);
     fS = tid >> 4; rS = tid & 15;
+    float dza = 0.f, dzb = 0.f;
+    if (spat) {   // dz[f] = ordered sum of the head waves' partials
+#pragma unroll
+      for (int w = 0; w < L::NWH; ++w) { dza += sTmp[w * TMPW + fS]; dzb += sTmp[w * TMPW + Sh::F + fS]; }
+    }
     {
       const bool act = spat && rS < Sh::P;
       float dwa[9], dwb[9], dba = 0.f, dbb = 0.f;
       if (act) {
-        row_bwd_w2<Sh>(sY1a, sY1b, sMaskA, sMaskB, sPool, fS, rS, sDz[fS], sDz[Sh::F + fS], dwa, dba, dwb, dbb);
+        float pw[L::RS];
+        load_row<Sh>(sPool + rS * L::RS, pw);
+        row_bwd_w<Sh>(sY1a, pw, sMaskA[fS * L::MS + rS], fS, rS, dza, dwa, dba);
+        row_bwd_w<Sh>(sY1b, pw, sMaskB[fS * L::MS + rS], fS, rS, dzb, dwb, dbb);
       } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { dwa[k] = 0.f; dwb[k] = 0.f; }
@@ -688,17 +757,33 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         slab[Sh::oB2b + fS] = first ? dbb : slab[Sh::oB2b + fS] + dbb;
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();       // the wave's own window reads of Y1 are done; neighbours never read them
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     STAMP(6);
     OPAQUE(tid);
     fS = tid >> 4; rS = tid & 15;
-    {   // dY1 rows overwrite Y1 in place (all window reads of Y1 are done); spec_a / lift_b bias and lift_b weight grads
+    {   // dY1 rows overwrite Y1 in place; spec_a / lift_b bias and lift_b weight gradients ride along
       float ga = 0.f, gb = 0.f, dwl[Sh::TB];
-      if (spat && rS < Sh::P) {
-        row_bwd_x2<Sh>(sY1a, sY1b, sMaskA, sMaskB, sPool, sAux, fS, rS, wA, wB, sDz[fS], sDz[Sh::F + fS], ga, gb, dwl);
-      } else {
 #pragma unroll
-        for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
+      for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
+      if (spat && rS < Sh::P) {
+        float dya[L::RS], dyb[L::RS];
+        row_bwd_x<Sh>(sY1a, sPool, sMaskA, fS, rS, wA, dza, dya);
+        row_bwd_x<Sh>(sY1b, sPool, sMaskB, fS, rS, wB, dzb, dyb);
+#pragma unroll
+        for (int c = 0; c < Sh::P; ++c) {
+          ga += dya[c];
+          gb += dyb[c];
+#pragma unroll
+          for (int k = 0; k < Sh::C2; ++k)
+#pragma unroll
+            for (int u = 0; u < Sh::S; ++u)
+#pragma unroll
+              for (int v = 0; v < Sh::S; ++v)
+                dwl[(k * Sh::S + u) * Sh::S + v] =
+                    fmaf(dyb[c], sAux[((Sh::S * rS + u) * Sh::SP + (Sh::S * c + v)) * Sh::C2 + k], dwl[(k * Sh::S + u) * Sh::S + v]);
+        }
       }
       ga = sum16(ga);
       gb = sum16(gb);
@@ -714,27 +799,35 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     STAMP(7);
 
-    // ------------------------------------------------------------------ P5: spec_a weight grad from the resident X tile
+    // ------------------------------------------------------------------ P5: spec_a weight grad, per wave:
+    //   dW[f][j] = sum_pix dY1a[f][pix] * X[pix][g*Cg + j]   for the wave's 4 channels f and its group's Cg bands.
+    //   lane <-> (band chunk cc, pixel slice sl); slice partials go through LDS and are summed in fixed order.
     OPAQUE(tid);
     STAMP(8);
-    {
-      constexpr int Q = L::Q, MB = L::MB, UNITS = L::UNITS, NSL = L::NSL;
-      const int u = tid % UNITS, sl = tid / UNITS;
-      const int cc = u % Q, mb = u / Q;
-      const int g = (4 * cc) / Sh::Cg;
-      float acc[MB][4];
+    if (wave < Sh::NB) {
+      constexpr int QG = L::QG, NSLW = L::NSLW;
+      const int ln = tid & 63;
+      const int cc = ln % QG, sl = ln / QG;
+      const int blk = wave;
+      const int g = (4 * blk) / Sh::M;
+      const int band0 = g * Sh::Cg + 4 * cc;
+      float acc[4][4];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.f;
-      if (sl < NSL) {
-        for (int pix = sl; pix < Sh::P2; pix += NSL) {
-          const float4 xv = *reinterpret_cast<const float4*>(sX + pix * Lds<Sh>::Cs + 4 * cc);
-          const float* dy = sY1a + pix * Sh::Fs + g * Sh::M + mb * MB;
+      for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.f;
+      if (sl < NSLW) {
+        const float* dyb = sY1a + (4 * blk) * L::FSZ;
+        for (int pix = sl; pix < Sh::P2; pix += NSLW) {
+          const float4 xv = *reinterpret_cast<const float4*>(sX + pix * L::Cs + band0);
+          const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
+          const float* dy = dyb + pr * L::RS + pc;
 #pragma unroll
-          for (int m = 0; m < MB; ++m) {
-            const float d = dy[m];
+          for (int m = 0; m < 4; ++m) {
+            const float d = dy[m * L::FSZ];
             acc[m][0] = fmaf(d, xv.x, acc[m][0]);
             acc[m][1] = fmaf(d, xv.y, acc[m][1]);
             acc[m][2] = fmaf(d, xv.z, acc[m][2]);
@@ -742,25 +835,31 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
           }
         }
       }
-      __syncthreads();   // X tile is dead: recycle it as [NSL][F*Cg] partials
       STAMP(9);
-      if (sl < NSL) {
+      // partial (sl, m, band) -> scratch.  OWN_SLICE: row (sl*4 + m) of this wave's private band columns of the X
+      // tile (only this wave ever touches them, and it has finished reading them: same wave, program order).
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float* scr = L::OWN_SLICE ? (sX + g * Sh::Cg) : (sGscr + blk * (NSLW * 4 * Sh::Cg));
+      constexpr int SROW = L::OWN_SLICE ? L::Cs : Sh::Cg;
+      if (sl < NSLW) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const int fo = g * Sh::M + mb * MB + m;
-          float* dst = sX + sl * (Sh::F * Sh::Cg) + fo * Sh::Cg + (4 * cc - g * Sh::Cg);
-          *reinterpret_cast<float4*>(dst) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-        }
+        for (int m = 0; m < 4; ++m)
+          *reinterpret_cast<float4*>(scr + (sl * 4 + m) * SROW + 4 * cc) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
       }
-      __syncthreads();
-      for (int e = tid; e < Sh::F * Sh::Cg; e += Sh::NT) {
-        float s = 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e = ln; e < 4 * Sh::Cg; e += 64) {
+        const int m = e / Sh::Cg, j = e - m * Sh::Cg;
+        float sacc = 0.f;
 #pragma unroll
-        for (int q = 0; q < NSL; ++q) s += sX[q * (Sh::F * Sh::Cg) + e];
-        slab[Sh::oA1w + e] = first ? s : slab[Sh::oA1w + e] + s;
+        for (int q = 0; q < NSLW; ++q) sacc += scr[(q * 4 + m) * SROW + j];
+        const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
+        slab[o] = first ? sacc : slab[o] + sacc;
       }
     }
-    __syncthreads();
+    LDS_BARRIER();
     STAMP(10);
   }
 }
@@ -801,7 +900,7 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
 
 // Compiled instances.  (C, C2, P, S, F, G, H)
 using ShapeHSI = Shape<200, 1, 11, 1, 40, 10, 64>;    // BASELINE configs 1-3: 200-band HSI + 1-band SAR/LiDAR, 11x11
-using ShapeHSI224 = Shape<224, 3, 11, 1, 40, 8, 64>;  // BASELINE config 4: 224-band HSI + 3-band SAR
+using ShapeHSI224 = Shape<224, 3, 11, 1, 32, 8, 64>;  // BASELINE config 4: 224-band HSI + 3-band SAR (gmf.width 32)
 using ShapePanMs = Shape<4, 1, 16, 4, 40, 1, 64>;     // the reference's own data: 4-band MS + PAN at 4x, patch 16
 using ShapeTiny = Shape<8, 1, 5, 4, 40, 2, 64>;       // small test scene (tests/golden/g9_trajectory.npz)
 using ShapeTiny1 = Shape<8, 1, 5, 1, 40, 2, 64>;      // small test scene, equal resolution

@@ -22,6 +22,7 @@ struct Shape {
   // reduction over patch rows is a 4-step shuffle inside a wavefront; at least 512 (head mapping)
   static constexpr int NT = (F * 16 <= 512) ? 512 : ((F * 16 + 63) / 64) * 64;
   static constexpr int NW = NT / 64;
+  static constexpr int NB = F / 4;          // channel blocks; wave b (< NB) owns channels 4b..4b+3 end to end
   // LDS row stride of the Y1 maps (floats); the X-tile stride is chosen in Lds<> (dmf_patch_kernel.hip)
   static constexpr int Fs = F + 1;          // odd: (channel,row)-mapped b32 reads of Y1 spread over all banks
   // flat parameter offsets (floats) — order documented in include/dmf.h
@@ -41,7 +42,7 @@ struct Shape {
 
   static_assert(C % G == 0 && F % G == 0, "groups must divide C and F");
   static_assert(Cg % 4 == 0, "bands per group must be a multiple of 4 (16-byte chunks)");
-  static_assert(F % 4 == 0, "feature width must be a multiple of 4");
+  static_assert(F % 4 == 0 && M % 4 == 0, "a wavefront owns a block of 4 channels inside one spectral group");
   static_assert(P <= 16, "one 16-lane group holds the rows of a patch");
   static_assert(F * 16 <= NT && NT <= 1024, "one 16-lane row group per channel");
   static_assert(H * 8 <= NT && H <= 64 && 4 * F2 <= NT, "head mapping");

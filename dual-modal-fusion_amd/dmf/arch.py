@@ -11,10 +11,11 @@ import torch
 
 
 def auto_groups(C, width):
-    """Largest G <= 16 with C % G == 0, width % G == 0 and 16-byte band chunks per group."""
+    """Largest G <= 16 with C % G == 0, width % G == 0, 16-byte band chunks per group ((C/G) % 4 == 0) and whole
+    4-channel blocks per group ((width/G) % 4 == 0: a wavefront owns 4 channels of one group)."""
     best = 1
     for g in range(1, 17):
-        if C % g == 0 and width % g == 0 and (C // g) % 4 == 0:
+        if C % g == 0 and width % g == 0 and (C // g) % 4 == 0 and (width // g) % 4 == 0:
             best = g
     return best
 

@@ -25,7 +25,8 @@ SHAPES = {
 def make_cfg(name):
     C, C2, P, S, K = SHAPES[name]
     return {'patch_size': P, 'Categories_Number': K, 'data_city': 's', 'DATA_DICT': {'s': {'size': [64, 64, C]}},
-            'scale': S, 'aux_bands': C2, 'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'scale': S, 'aux_bands': C2,
+            'gmf': {'width': 32 if name == 'hsi224' else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def nets(name, seed=0):

@@ -17,9 +17,9 @@ from dmf.engine import Scene
 from function.function import data_padding, data_padding_aux
 from model.gmfnet import Net
 
-NAMES = ['P0 load X+aux', 'P1 spec_a+lift_b', 'P2 dw3x3 fwd+pool', 'P3 head fwd+CE', 'P3b head bwd (dh,dz)',
-         'P4a dw3x3 dW/db', 'P4b dY1 in place', 'P5a lift/bias grads', 'P5b spec_a dW loop',
-         'P5c partial reduce']
+NAMES = ['issue gather + aux branch fwd', 'wait window (barrier)', 'spec_a + spat_a fwd + barrier', 'fc1, wave-0 fc2/CE/dh',
+         'dz partials + barrier', 'dw3x3 dW/db', 'dY1 in place + bias/lift grads', '-', 'spec_a dW loop',
+         'partials + slab + final barrier']
 
 
 def main():
