@@ -28,9 +28,26 @@ struct KArgs {   // must match dmf_patch_kernel.hip
   float* ws_dh;
   float* ws_dl;
   int32_t* adam_step;
+  unsigned short* tokA;
+  unsigned short* tokB;
+  float* zout;
   int32_t K;
 };
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2 };
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3 };
+
+struct AttnArgs {   // must match dmf_attention.hip
+  const unsigned short* tokA;
+  const unsigned short* tokB;
+  const float* zin;
+  const float* theta;
+  const float* pool;
+  float* logits;
+  int32_t* pred;
+  int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
+  int32_t B, K;
+};
+int attn_shape_supported(const dmf_shape& s);
+hipError_t attn_dispatch(const dmf_shape& s, const AttnArgs& a, hipStream_t st);
 
 #ifdef DMF_STAMPS
 hipError_t set_stamps(unsigned long long* p);
@@ -50,7 +67,9 @@ static int check(hipError_t e, const char* what) {
   return 1;
 }
 
-static Layout layout_of(const dmf_shape& s) { return make_layout(s.C, s.C2, s.P, s.S, s.F, s.G, s.H, s.K); }
+static Layout layout_of(const dmf_shape& s) {
+  return make_layout(s.C, s.C2, s.P, s.S, s.F, s.G, s.H, s.K, s.attention, s.E);
+}
 
 // ------------------------------------------------------------------------------ gradient reduction (+Adam)
 //   conv params  : grad[p] = sum_blk slab[blk][p]
@@ -252,6 +271,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
                      int32_t* pred, void* workspace, int32_t* adam_step, void* stream) {
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr) return fail("%s", "null argument");
   if (dmf_shape_supported(s)) return 1;
+  if (s->attention && mode != MODE_FWD) return fail("%s", "training with the attention block is not built yet (forward only)");
   if (in->B < 0) return fail("%s", "negative batch");
   if (in->B == 0) return 0;
   if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");
@@ -284,9 +304,39 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
   return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }
 
+int64_t dmf_attn_workspace_bytes(const dmf_shape* s, int32_t B) {
+  if (s == nullptr || B < 0) return -1;
+  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4);      // two bf16 token maps + pooled z per patch
+}
+
+int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                         void* workspace, float* logits, int32_t* pred, void* stream) {
+  if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || workspace == nullptr || logits == nullptr)
+    return fail("%s", "null argument");
+  if (!s->attention) return fail("%s", "dmf_forward_attn needs shape->attention == 1");
+  if (dmf_shape_supported(s)) return 1;
+  if (!attn_shape_supported(*s)) return fail("%s", "no compiled attention instance for this shape (E = 96, heads = 3, F = 40)");
+  if (in->B <= 0) return in->B == 0 ? 0 : fail("%s", "negative batch");
+  const Layout L = layout_of(*s);
+  unsigned short* tokA = static_cast<unsigned short*>(workspace);
+  unsigned short* tokB = tokA + (size_t)in->B * 128 * 64;
+  float* z = reinterpret_cast<float*>(tokB + (size_t)in->B * 128 * 64);
+  KArgs a{};
+  a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
+  a.tokA = tokA; a.tokB = tokB; a.zout = z;
+  if (check(patch_dispatch(*s, MODE_TOKENS, a, static_cast<hipStream_t>(stream)), "token kernel launch")) return 1;
+  AttnArgs t{};
+  t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w; t.logits = logits; t.pred = pred;
+  t.oWq = L.off[12]; t.oWk = L.off[13]; t.oWv = L.off[14]; t.oWo = L.off[15];
+  t.oFc1w = L.off[8]; t.oFc1b = L.off[9]; t.oFc2w = L.off[10]; t.oFc2b = L.off[11];
+  t.B = in->B; t.K = s->K;
+  return check(attn_dispatch(*s, t, static_cast<hipStream_t>(stream)), "attention kernel launch");
+}
+
 int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                     float* logits, int32_t* pred, void* stream) {
   if (logits == nullptr) return fail("%s", "null logits");
+  if (s != nullptr && s->attention) return fail("%s", "attention network: use dmf_forward_attn");
   return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, nullptr, stream);
 }
 

@@ -32,7 +32,7 @@
 
 namespace dmf {
 
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2 };
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3 };   // TOKENS: conv stages only, for the attention kernel
 
 // Diagnostic build only (-DDMF_STAMPS, tools/phase_profile.py): per-phase s_memtime stamps of wave 0, written to a
 // buffer nothing else reads.  The shipped library contains no stamp.
@@ -69,6 +69,9 @@ struct KArgs {
   float* ws_dh;  // [B][H]
   float* ws_dl;  // [B][KMAX]
   int32_t* adam_step;   // device step counter to advance (nullable)
+  unsigned short* tokA; // MODE_TOKENS: bf16 token maps [B][128][64] (tokens x channels, zero padded) of both branches
+  unsigned short* tokB;
+  float* zout;          // MODE_TOKENS: pooled features [B][2F] before attention
   int32_t K;
 };
 
@@ -152,7 +155,8 @@ struct Lds {
   // banks (MI355X_MICROARCH.md §LDS); the pad is dropped (2-way conflict) only where it would not fit in 160 KiB.
   static constexpr int CsPad = Sh::C + ((((Sh::C / 4) & 1) == 0) ? 4 : 0);
   static constexpr int Cs = (Sh::P2 * CsPad + REST <= 40960) ? CsPad : Sh::C;
-  static constexpr int SCR = Sh::P2 * Cs;                                    // X tile
+  static constexpr int TOKSCR = (Sh::P2 <= 128) ? 2 * 128 * 72 / 2 : 0;      // MODE_TOKENS staging (floats)
+  static constexpr int SCR = cmax(Sh::P2 * Cs, TOKSCR);                      // X tile (later: token staging)
   static_assert(!OWN_SLICE || NSLW * 4 <= Sh::P2, "own-slice scratch needs NSLW*4 pixel rows");
   // offsets in floats
   static constexpr int oX = 0;
@@ -176,7 +180,8 @@ struct Lds {
   static constexpr int W2ROWS = W2ROWS_ > KMAX ? KMAX : (W2ROWS_ < 0 ? 0 : W2ROWS_);
   static constexpr int TOTAL = oW2 + KMAX + W2ROWS * Sh::H;
   // LDS-DMA gather of the window: 256-float (1 KiB) pieces of the padded LDS image, NXW pieces per wave
-  static constexpr int NCH = (SCR + 255) / 256;
+  static constexpr int XSZ = Sh::P2 * Cs;                           // the window image itself
+  static constexpr int NCH = (XSZ + 255) / 256;
   static constexpr int NXW = (NCH + Sh::NW - 1) / Sh::NW;
   static constexpr int NAUXI = (Sh::PB * Sh::C2 + 63) / 64;
   static constexpr int BYTES = TOTAL * 4;
@@ -206,9 +211,9 @@ __device__ __forceinline__ void x_gather_dma(const dmf_input& in, int b, float* 
     const int o = k * 256 + 4 * lane;                       // float offset inside the LDS image
     const int pix = o / L::Cs, within = o - pix * L::Cs;
     const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
-    const bool data = o < L::SCR && within < Sh::C;
+    const bool data = o < L::XSZ && within < Sh::C;
     const float* src = base + (data ? (unsigned)((pr * in.Wp + pc) * Sh::C + within) : 0u);
-    if (o < L::SCR)
+    if (o < L::XSZ)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sX + k * 256), 16, 0, 0);
   }
@@ -323,7 +328,7 @@ __device__ __forceinline__ void load_dww(const float* base, float w[12]) {
 // forward of one branch: y = bias + depthwise 3x3 (zero pad 1); ReLU mask word; pooled partial sum of the row
 template <class Sh>
 __device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>::RS], int f, int r, const float w[9],
-                                        float bias, uint32_t& mask, float& z) {
+                                        float bias, uint32_t& mask, float& z, float* yout = nullptr) {
   using L = Lds<Sh>;
   const float m0 = r > 0 ? 1.f : 0.f, m2 = r < Sh::P - 1 ? 1.f : 0.f;
   const int r0 = r > 0 ? r - 1 : 0, r2 = r < Sh::P - 1 ? r + 1 : Sh::P - 1;
@@ -350,6 +355,7 @@ __device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>:
       mask |= (1u << c);
       z = fmaf(pw[c], y, z);
     }
+    if (yout != nullptr) yout[c] = fmaxf(y, 0.f);
   }
 }
 
@@ -552,11 +558,12 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // spat_b: depthwise 3x3 + ReLU + pooling on the wave's own 4 channels
     float zb = 0.f;
+    float ytokA[Sh::P], ytokB[Sh::P];          // MODE_TOKENS: this thread's rows of the two feature maps
     if (spat && rS < Sh::P) {
       float pwrow[L::RS];
       load_row<Sh>(sPool + rS * L::RS, pwrow);
       uint32_t mkb;
-      row_fwd<Sh>(sY1b, pwrow, fS, rS, wB, bB, mkb, zb);
+      row_fwd<Sh>(sY1b, pwrow, fS, rS, wB, bB, mkb, zb, MODE == MODE_TOKENS ? ytokB : nullptr);
       sMaskB[fS * L::MS + rS] = mkb;
     }
     zb = sum16(zb);
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         uint32_t mka;
         float pwrow[L::RS];
         load_row<Sh>(sPool + rS * L::RS, pwrow);
-        row_fwd<Sh>(sY1a, pwrow, fS, rS, wA, bA, mka, za);
+        row_fwd<Sh>(sY1a, pwrow, fS, rS, wA, bA, mka, za, MODE == MODE_TOKENS ? ytokA : nullptr);
         sMaskA[fS * L::MS + rS] = mka;
       }
       za = sum16(za);
@@ -630,6 +637,34 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     }
     LDS_BARRIER();
     STAMP(3);
+    if constexpr (MODE == MODE_TOKENS && Sh::P2 <= 128) {
+      // every wave is past spec_a, so the window is dead: stage the two [128][64] bf16 token maps in its place
+      // (row stride 72 halves keeps the 2-byte scatter off a single bank), then copy them out in 16-byte pieces
+      constexpr int TS = 72;
+      unsigned short* sTok = reinterpret_cast<unsigned short*>(sX);
+      static_assert(2 * 128 * TS * 2 <= L::SCR * 4, "token staging fits in the window region");
+      static_assert(L::NCH * 256 >= 0, "");
+      for (int i = tid; i < 2 * 128 * TS / 2; i += Sh::NT) reinterpret_cast<uint32_t*>(sTok)[i] = 0u;
+      LDS_BARRIER();
+      if (spat && rS < Sh::P) {
+#pragma unroll
+        for (int c = 0; c < Sh::P; ++c) {
+          const int t = rS * Sh::P + c;
+          sTok[t * TS + fS] = __builtin_bit_cast(unsigned short, (__bf16)ytokA[c]);
+          sTok[128 * TS + t * TS + fS] = __builtin_bit_cast(unsigned short, (__bf16)ytokB[c]);
+        }
+      }
+      LDS_BARRIER();
+      for (int i = tid; i < 2 * 128 * 8; i += Sh::NT) {          // 2 maps x 128 tokens x 8 pieces of 16 bytes
+        const int mp = i >> 10, rem = i & 1023, t = rem >> 3, pc8 = rem & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(sTok + mp * 128 * TS + t * TS + pc8 * 8);
+        unsigned short* dst = (mp ? a.tokB : a.tokA) + ((size_t)b * 128 + t) * 64 + pc8 * 8;
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+      if (tid < Sh::F2) a.zout[(size_t)b * Sh::F2 + tid] = sZ[tid];
+      LDS_BARRIER();
+      continue;
+    }
 
     // ------------------------------------------------------------------ P3: head
     {   // fc1 + ReLU, all waves: thread (jH, pH) holds W1[jH][pH + 8m]
@@ -870,7 +905,7 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
   using L = Lds<Sh>;
   const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
   hipError_t e = hipSuccess;
-  static bool attr_done[3] = {false, false, false};
+  static bool attr_done[4] = {false, false, false, false};
   auto set_attr = [&](const void* fn, int m) {
     if (!attr_done[m]) {
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
@@ -888,6 +923,11 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
       set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_TRAIN>), 1);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL((patch_kernel<Sh, MODE_TRAIN>), dim3(grid), dim3(Sh::NT), L::BYTES, st, a);
+      break;
+    case MODE_TOKENS:
+      set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_TOKENS>), 3);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((patch_kernel<Sh, MODE_TOKENS>), dim3(grid), dim3(Sh::NT), L::BYTES, st, a);
       break;
     default:
       set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_BWD>), 2);
@@ -911,7 +951,7 @@ static bool matches(const dmf_shape& s) {
 }
 
 int patch_shape_supported(const dmf_shape& s) {
-  if (s.K < 1 || s.K > KMAX || s.attention != 0) return 0;
+  if (s.K < 1 || s.K > KMAX) return 0;
   return matches<ShapeHSI>(s) || matches<ShapeHSI224>(s) || matches<ShapePanMs>(s) || matches<ShapeTiny>(s) ||
          matches<ShapeTiny1>(s);
 }

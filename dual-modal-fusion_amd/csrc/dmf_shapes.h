@@ -50,21 +50,23 @@ struct Shape {
 
 // run-time mirror of the layout (host side + generic kernels)
 struct Layout {
-  int C, C2, P, S, F, G, H, K;
+  int C, C2, P, S, F, G, H, K, attention, E;
   int Cg, TB, F2, NCONV, SLAB;
   int64_t off[17];
   int64_t n_params;
 };
 
-inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int K) {
+inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int K, int attention = 0, int E = 0) {
   Layout L{};
-  L.C = C; L.C2 = C2; L.P = P; L.S = S; L.F = F; L.G = G; L.H = H; L.K = K;
+  L.C = C; L.C2 = C2; L.P = P; L.S = S; L.F = F; L.G = G; L.H = H; L.K = K; L.attention = attention; L.E = E;
   L.Cg = C / G; L.TB = C2 * S * S; L.F2 = 2 * F;
   int64_t o = 0;
   const int64_t sizes[12] = {(int64_t)F * L.Cg, F, (int64_t)F * 9, F, (int64_t)F * L.TB, F, (int64_t)F * 9, F,
                              (int64_t)H * L.F2, H, (int64_t)K * H, K};
   for (int i = 0; i < 12; ++i) { L.off[i] = o; o += sizes[i]; }
-  for (int i = 12; i < 17; ++i) L.off[i] = o;
+  const int64_t asz = attention ? (int64_t)E * F : 0;          // attn_wq, attn_wk, attn_wv [E,F], attn_wo [F,E]
+  for (int i = 12; i < 16; ++i) { L.off[i] = o; o += asz; }
+  L.off[16] = o;
   L.NCONV = (int)L.off[8];
   L.SLAB = (L.NCONV + 31) & ~31;
   L.n_params = o;

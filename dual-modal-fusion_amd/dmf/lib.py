@@ -40,6 +40,8 @@ def _load():
         'dmf_param_layout': (i32, [SP, C.POINTER(i64)]),
         'dmf_workspace_bytes': (i64, [SP, i32]),
         'dmf_forward': (i32, [SP, IP, vp, vp, vp, vp, vp]),
+        'dmf_attn_workspace_bytes': (i64, [SP, i32]),
+        'dmf_forward_attn': (i32, [SP, IP, vp, vp, vp, vp, vp, vp]),
         'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
         'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
@@ -139,6 +141,15 @@ def check_xy_bounds(shape, sceneA, sceneB, xy_host):
 
 def forward(shape, inp, theta, pool_w, logits, pred=None):
     check(_lib.dmf_forward(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(logits), _ptr(pred), _stream()))
+
+
+def attn_workspace_bytes(shape, B):
+    return _lib.dmf_attn_workspace_bytes(C.byref(shape), B)
+
+
+def forward_attn(shape, inp, theta, pool_w, ws, logits, pred=None):
+    check(_lib.dmf_forward_attn(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(ws), _ptr(logits),
+                                _ptr(pred), _stream()))
 
 
 def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, adam_step_dev=None):

@@ -9,6 +9,8 @@ oracle/gmfnet_ref.py.
 All arithmetic runs in libdmf_hip.so (hand-written HIP, include/dmf.h); torch supplies parameters,
 autograd plumbing and device memory only.  There is no CPU path: calling the net off-GPU raises.
 """
+import math
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,7 @@ from dmf.arch import anchor_pool_weights, arch_from_cfg
 
 PARAM_ORDER = ('spec_a.weight', 'spec_a.bias', 'spat_a.weight', 'spat_a.bias', 'lift_b.weight', 'lift_b.bias',
                'spat_b.weight', 'spat_b.bias', 'fc1.weight', 'fc1.bias', 'fc2.weight', 'fc2.bias')
+ATTN_ORDER = ('attn_wq', 'attn_wk', 'attn_wv', 'attn_wo')
 
 
 class _GmfFunction(torch.autograd.Function):
@@ -57,7 +60,14 @@ class Net(nn.Module):
         self.lift_b = nn.Conv2d(a['C2'], a['F'], a['S'], stride=a['S'])
         self.spat_b = nn.Conv2d(a['F'], a['F'], 3, padding=1, groups=a['F'])
         if a['attention']:
-            raise NotImplementedError('cross-modal attention (gmf.attention=1) is not built yet in the HIP path')
+            # created here, in the order and with the initialiser of the CPU statement (oracle/gmfnet_ref.py)
+            E = a['E']
+            self.attn_wq = nn.Parameter(torch.empty(E, a['F']))
+            self.attn_wk = nn.Parameter(torch.empty(E, a['F']))
+            self.attn_wv = nn.Parameter(torch.empty(E, a['F']))
+            self.attn_wo = nn.Parameter(torch.empty(a['F'], E))
+            for w in (self.attn_wq, self.attn_wk, self.attn_wv, self.attn_wo):
+                nn.init.uniform_(w, -1.0 / math.sqrt(w.shape[1]), 1.0 / math.sqrt(w.shape[1]))
         self.fc1 = nn.Linear(2 * a['F'], a['H'])
         self.fc2 = nn.Linear(a['H'], a['K'])
         self.register_buffer('pool_w', anchor_pool_weights(a['P'], a['sigma']))
@@ -71,7 +81,7 @@ class Net(nn.Module):
     # ---- flat parameter vector ------------------------------------------------------------------
     def _named(self):
         d = dict(self.named_parameters())
-        return [d[k] for k in PARAM_ORDER]
+        return [d[k] for k in PARAM_ORDER + (ATTN_ORDER if self.arch['attention'] else ())]
 
     def flat_parameters(self):
         """One contiguous fp32 vector holding every parameter in the library's order; the nn.Parameters are
@@ -106,6 +116,16 @@ class Net(nn.Module):
         a = ms.contiguous().float()
         b = pan.contiguous().float()
         theta = self.flat_parameters()
+        if self.arch['attention']:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise lib.DmfError('training with gmf.attention=1 is not built yet: the HIP attention block is forward '
+                                   'only (wrap the call in torch.no_grad())')
+            inp = lib.input_patches(self.shape, a, b)
+            B = a.shape[0]
+            logits = torch.empty(B, self.arch['K'], device=a.device, dtype=torch.float32)
+            ws = torch.empty(lib.attn_workspace_bytes(self.shape, B), device=a.device, dtype=torch.uint8)
+            lib.forward_attn(self.shape, inp, theta, self.pool_w, ws, logits)
+            return logits
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # route the flat gradient back to the individual parameters through a differentiable cat
             theta_g = torch.cat([p.reshape(-1) for p in self._named()])

@@ -114,28 +114,30 @@ class Net(nn.Module):
         return ya, yb
 
     def attention(self, ya, yb):
+        """Cross-modal attention, Ta' = Ta + bf16(O) bf16(Wo)^T with O = softmax(Qs K^T) V per head.
+
+        With `mfma_bf16` every matrix-core operand is rounded to bf16 (round-to-nearest-even) and every product
+        accumulates in fp32, which is what the HIP kernel's `v_mfma_f32_16x16x32_bf16` does:
+          q = bf16(Ta) bf16(Wq)^T, k = bf16(Tb) bf16(Wk)^T, v = bf16(Tb) bf16(Wv)^T      (projections)
+          s = bf16(q / sqrt(dh)) bf16(k)^T;  p = softmax(s) in fp32;  o = bf16(p) bf16(v)
+        Gradients pass straight through the roundings (the backward is not built in HIP yet)."""
         A = self.arch
         B, Fw, P, _ = ya.shape
         T = P * P
         nh, E = A['heads'], A['E']
         dh = E // nh
+        r = _ste_bf16 if A['mfma_bf16'] else (lambda x: x)
         ta = ya.reshape(B, Fw, T).transpose(1, 2)            # [B, T, F]
         tb = yb.reshape(B, Fw, T).transpose(1, 2)
-        q = (ta @ self.attn_wq.t()).reshape(B, T, nh, dh).transpose(1, 2)   # [B, nh, T, dh]
-        k = (tb @ self.attn_wk.t()).reshape(B, T, nh, dh).transpose(1, 2)
-        v = (tb @ self.attn_wv.t()).reshape(B, T, nh, dh).transpose(1, 2)
-        scale = 1.0 / math.sqrt(dh)
-        if A['mfma_bf16']:
-            # bf16 MFMA operands, fp32 accumulate: QK^T takes bf16(Q*scale), bf16(K); PV takes bf16(P), bf16(V)
-            s = _ste_bf16(q * scale) @ _ste_bf16(k).transpose(-1, -2)
-            p = torch.softmax(s, dim=-1)
-            o = _ste_bf16(p) @ _ste_bf16(v)
-        else:
-            s = (q * scale) @ k.transpose(-1, -2)
-            p = torch.softmax(s, dim=-1)
-            o = p @ v
+        q = (r(ta) @ r(self.attn_wq).t()).reshape(B, T, nh, dh).transpose(1, 2)   # [B, nh, T, dh]
+        k = (r(tb) @ r(self.attn_wk).t()).reshape(B, T, nh, dh).transpose(1, 2)
+        v = (r(tb) @ r(self.attn_wv).t()).reshape(B, T, nh, dh).transpose(1, 2)
+        scale = torch.tensor(1.0 / math.sqrt(dh), dtype=torch.float32)
+        s = r(q * scale) @ r(k).transpose(-1, -2)
+        p = torch.softmax(s, dim=-1)
+        o = r(p) @ r(v)
         o = o.transpose(1, 2).reshape(B, T, E)
-        ta2 = ta + o @ self.attn_wo.t()
+        ta2 = ta + r(o) @ r(self.attn_wo).t()
         return ta2.transpose(1, 2).reshape(B, Fw, P, P)
 
     def pooled(self, ya, yb):
