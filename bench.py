@@ -35,7 +35,7 @@ def make_cfg(args):
     return {'patch_size': args.patch, 'Categories_Number': K, 'data_city': 'syn',
             'DATA_DICT': {'syn': {'size': [args.size, args.size, args.bands], 'color': class_colors(K)}},
             'scale': 1, 'aux_bands': args.aux_bands,
-            'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'gmf': {'width': 32 if args.bands == 224 else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def build_problem(args, cfg):
@@ -80,7 +80,7 @@ def main():
     ap.add_argument('--classes', type=int, default=16)
     ap.add_argument('--train-rate', type=float, default=0.10)
     ap.add_argument('--steps-per-graph', type=int, default=50, help='0 = eager launches')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (rank 0, N=1 only)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='CPU baseline budget (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 
@@ -94,13 +94,20 @@ def main():
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0, gloo instead of RCCL
+    if os.environ.get('DMF_SINGLE_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('DMF_DIST_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from dmf import lib
@@ -193,7 +200,7 @@ def main():
                    'launch': ('hipGraph x%d steps' % spg) if spg else 'eager'},
         'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK, 'traffic': traffic,
-                     'kernel': 'dmf::patch_kernel<Shape<200,1,11,1,40,10,64>, MODE_TRAIN>', 'kernel_ms': kern_ms,
+                     'kernel': 'dmf::patch_kernel<Shape<%d,%d,%d,1,%d,..>, MODE_TRAIN>' % (C, C2, P, net.arch['F']), 'kernel_ms': kern_ms,
                      'algorithmic_bytes_per_launch': B * alg_patch},
         'step_frac_of_hbm_roof': value / world * (alg_patch + 28.0 * eng.theta.numel() / B) / HBM_PEAK,
     }
@@ -242,10 +249,36 @@ def main():
                                'kind': 'port',
                                'sample': 'first %d of the same train steps (batch %d), oracle/solver_ref.py on torch-CPU fp32, %.1f s'
                                          % (n_cpu[0], B, t_cpu)}
-        # parity of the first steps' losses (same init, same batches)
+        # parity of the first steps' losses (same init, same batches) ...
         n_cmp = min(len(cpu_losses), len(losses))
         if n_cmp:
-            out['cpu_baseline']['max_abs_loss_diff_first_%d_steps' % n_cmp] = float(np.max(np.abs(np.array(cpu_losses[:n_cmp]) - losses[:n_cmp])))
+            d = np.abs(np.array(cpu_losses[:n_cmp]) - losses[:n_cmp])
+            out['cpu_baseline']['max_abs_loss_diff_first_20_steps'] = float(d[:20].max())
+            out['cpu_baseline']['max_abs_loss_diff_first_%d_steps' % n_cmp] = float(d.max())
+        # kappa of the CPU forward path on the GPU-trained weights (same weights, same patches: must be identical)
+        n_kt = min(n_test, 2048)
+        ref_f = RefNet(cfg)
+        ref_f.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        m_f, _ = solver_ref.evaluate(ref_f, MS, PAN, xy_tab[test[:n_kt]], lab_tab[test[:n_kt]], args.classes + 1, P, 1)
+        m_g = ev_eng.confusion(xy_tab[test[:n_kt]], lab_tab[test[:n_kt]]).cpu().numpy().astype(np.float64)
+        out['kappa'].update({'same_weights_test_patches': int(n_kt), 'same_weights_gpu': aa_oa_quiet(m_g)[2],
+                             'same_weights_cpu_forward': aa_oa_quiet(m_f)[2],
+                             'same_weights_predictions_differing': int(np.abs(m_f - m_g).sum() // 2)})
+        # ... and kappa after the SAME number of steps on the same held-out patches: CPU net vs a fresh GPU run
+        # (two fp32 ADAM trajectories drift apart chaotically once summation orders differ; this is reported, the
+        # same-weights figures above are the parity claim)
+        n_k = len(cpu_losses)
+        if n_k:
+            m_cpu, _ = solver_ref.evaluate(ref, MS, PAN, xy_tab[test[:n_kt]], lab_tab[test[:n_kt]], args.classes + 1, P, 1)
+            net2 = Net(cfg).to(dev)
+            net2.load_state_dict(init_state)
+            eng2 = TrainEngine(net2, scene, B, lr=1e-3)
+            eng2.load_plan(xy_tab[mine[:n_k * B]], lab_tab[mine[:n_k * B]])
+            eng2.run_plan(n_k, 0)
+            m_gpu = EvalEngine(net2, scene, 2048).confusion(xy_tab[test[:n_kt]], lab_tab[test[:n_kt]]).cpu().numpy().astype(np.float64)
+            out['kappa'].update({'parity_steps': n_k, 'parity_test_patches': int(n_kt),
+                                 'cpu_after_parity_steps': aa_oa_quiet(m_cpu)[2], 'gpu_after_parity_steps': aa_oa_quiet(m_gpu)[2],
+                                 'confusion_entries_differing': int(np.abs(m_cpu - m_gpu).sum() // 2)})
     print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

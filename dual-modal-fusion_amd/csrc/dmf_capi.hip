@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
   const int jj = tid & 15, ch = tid >> 4;
   const int64_t p = (int64_t)blockIdx.x * 16 + jj;
   float acc = 0.f;
+  // the thread that will apply ADAM fetches its state now, so that latency overlaps the gradient reads
+  float th0 = 0.f, m0 = 0.f, v0 = 0.f;
+  if (ch == 0 && p < a.n && a.theta != nullptr) { th0 = a.theta[p]; m0 = a.m[p]; v0 = a.v[p]; }
   if (p < a.n) {
     if (p < a.NCONV) {
       const int per = (a.nblk + 15) / 16;
@@ -190,7 +193,13 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
       for (int i = 0; i < w; ++i) t[i] += t[i + w];
     const float g = t[0];
     if (a.grad != nullptr) a.grad[p] = g;
-    if (a.theta != nullptr) adam_update(a.theta, a.m, a.v, p, g, a.lr, a.b1, a.b2, a.eps, bcs[0], bcs[1]);
+    if (a.theta != nullptr) {
+      const float mn = m0 + (g - m0) * (1.f - a.b1);
+      const float vn = v0 * a.b2 + (1.f - a.b2) * g * g;
+      a.m[p] = mn;
+      a.v[p] = vn;
+      a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
+    }
   }
 }
 

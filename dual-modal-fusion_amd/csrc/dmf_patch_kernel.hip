@@ -856,10 +856,15 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.f;
       if (sl < NSLW) {
         const float* dyb = sY1a + (4 * blk) * L::FSZ;
+        constexpr int DR = NSLW / Sh::P, DC = NSLW - DR * Sh::P;      // pix += NSLW  ->  row += DR (+1), col += DC (-P)
+        int pr = sl / Sh::P, pc = sl - pr * Sh::P;
+        const float* xp = sX + sl * L::Cs + band0;
         for (int pix = sl; pix < Sh::P2; pix += NSLW) {
-          const float4 xv = *reinterpret_cast<const float4*>(sX + pix * L::Cs + band0);
-          const int pr = pix / Sh::P, pc = pix - pr * Sh::P;
+          const float4 xv = *reinterpret_cast<const float4*>(xp);
           const float* dy = dyb + pr * L::RS + pc;
+          xp += NSLW * L::Cs;
+          pr += DR; pc += DC;
+          if (pc >= Sh::P) { pc -= Sh::P; pr += 1; }
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const float d = dy[m * L::FSZ];

@@ -1,0 +1,76 @@
+"""GPU: the data-parallel engine path (world_size 2).  Two processes share the one GPU of the test box and talk
+over gloo (RCCL refuses two ranks on one device); the code path is the one `bench.py --gpus N` runs over RCCL:
+dmf_grad_reduce -> all-reduce(sum) of ONE flat gradient -> dmf_adam_step(grad_scale = 1/N).  After 3 steps the
+2-rank parameters must equal those of a single process that trains on the concatenated global batches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'dual-modal-fusion_amd')
+CFG = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [20, 20, 8]}}, 'scale': 1,
+       'aux_bands': 1, 'gmf': {'width': 40}}
+B, STEPS = 32, 3
+
+
+def _problem():
+    sys.path[:0] = [PKG, REPO]
+    from dmf import synth
+    from function.function import data_padding, data_padding_aux
+    primary, aux, label = synth.make_scene(20, 20, 8, 1, 1, n_classes=4, seed=3)
+    MS = data_padding(primary, CFG, 'ms').astype(np.float32)
+    PAN = data_padding_aux(aux, CFG).astype(np.float32)
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.integers(0, 20, 2 * B * STEPS), rng.integers(0, 20, 2 * B * STEPS)], 1).astype(np.int32)
+    lab = np.maximum(label[xy[:, 0], xy[:, 1]].astype(np.int32), 1)
+    return MS, PAN, xy, lab
+
+
+def _train(rank, world, port, q):
+    import torch.distributed as dist
+    MS, PAN, xy, lab = _problem()
+    from dmf.engine import Scene, TrainEngine
+    from dmf.parallel import shard_batch
+    from model.gmfnet import Net
+    pg = None
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        pg = dist.group.WORLD
+    torch.manual_seed(0)
+    net = Net(CFG).to('cuda:0')
+    eng = TrainEngine(net, Scene(MS, PAN, 'cuda:0'), (2 * B) // world, lr=1e-2, process_group=pg)
+    gxy, glab = xy.reshape(STEPS, 2 * B, 2), lab.reshape(STEPS, 2 * B)
+    lo, hi = shard_batch(2 * B, rank, world)
+    eng.load_plan(gxy[:, lo:hi].reshape(-1, 2), glab[:, lo:hi].reshape(-1))
+    eng.run_plan(STEPS, 0)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(eng.theta.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_dp_equals_single_rank_global_batch():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [ctx.Process(target=_train, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    two = q.get(timeout=300)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    p1 = ctx.Process(target=_train, args=(0, 1, port, q))
+    p1.start()
+    one = q.get(timeout=300)
+    p1.join(120)
+    assert p1.exitcode == 0
+    err = np.abs(two - one).max()
+    print('2-rank vs 1-rank parameters after %d steps: max abs diff %.2e' % (STEPS, err))
+    assert err < 2e-5
