@@ -121,13 +121,18 @@ def main():
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     scene = Scene(MS, PAN, dev)
-    eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg)
+    comm = None
+    if world > 1 and os.environ.get('DMF_ALLREDUCE', 'xgmi') == 'xgmi':
+        from dmf import xgmi
+        comm = xgmi.create(sum(p.numel() for p in net.parameters()), pg,     # None on every rank if it cannot be proven
+                           timeout_ms=int(os.environ.get('DMF_XGMI_TIMEOUT_MS', 20000)))
+    eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=comm)
 
     total = W_steps + K_steps
     plan_idx = make_plan(train, total, B * world, seed=1)                 # global batches of world*B
     mine = plan_idx.reshape(total, world, B)[:, rank, :].reshape(-1)      # this rank's contiguous shard per step
     eng.load_plan(xy_tab[mine], lab_tab[mine])
-    spg = args.steps_per_graph if world == 1 else 0
+    spg = args.steps_per_graph if (world == 1 or comm is not None) else 0   # RCCL path: eager launches
 
     def sync():
         torch.cuda.synchronize()
@@ -150,6 +155,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if comm is not None and comm.status() != 0:
+        raise SystemExit('rank %d: a gradient exchange timed out waiting for a peer — the timing is void' % rank)
     losses = eng.mean_losses().numpy() if world == 1 else np.zeros(0)
     value = world * B * K_steps / dt
 
@@ -197,7 +204,9 @@ def main():
         'config': {'workload': 'configs[1]: synthetic %dx%d scene, %d-band HSI + %d-band SAR, %dx%d patches, %d logits, '
                                'batch %d per GPU, fused HIP fwd+CE+bwd+Adam' % (args.size, args.size, C, C2, P, P, args.classes + 1, B),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                   'launch': ('hipGraph x%d steps' % spg) if spg else 'eager'},
+                   'launch': ('hipGraph x%d steps' % spg) if spg else 'eager',
+                   'allreduce': 'none' if world == 1 else ('xgmi one-shot, fused in the reduce+Adam launch' if comm is not None
+                                                           else 'rccl all_reduce of one flat fp32 gradient')},
         'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK, 'traffic': traffic,
                      'kernel': 'dmf::patch_kernel<Shape<%d,%d,%d,1,%d,..>, MODE_TRAIN>' % (C, C2, P, net.arch['F']), 'kernel_ms': kern_ms,

@@ -9,6 +9,7 @@
 
 #include "../../include/dmf.h"
 #include "dmf_shapes.h"
+#include "dmf_xgmi.h"
 
 namespace dmf {
 
@@ -85,6 +86,8 @@ struct ReduceArgs {
   const int32_t* step_dev;            // optional device-side step count (overrides bc1 / bc2_sqrt)
   int32_t* cursor_dev;                // optional epoch-plan cursor to advance
   const float* loss; float* loss_hist;
+  XgmiDev x;                          // x.world > 1: exchange the gradient with the peer ranks before Adam
+  float grad_scale; int seq_bias;
 };
 
 // bias corrections from a device-resident step count, in double like torch's host-side scalars
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
     bcs[1] = bc2s;
   }
   __syncthreads();
+  float g = 0.f;
   if (ch == 0 && p < a.n) {
     float t[16];
 #pragma unroll
@@ -191,7 +195,11 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
     for (int w = 8; w > 0; w >>= 1)
 #pragma unroll
       for (int i = 0; i < w; ++i) t[i] += t[i + w];
-    const float g = t[0];
+    g = t[0];
+  }
+  if (a.x.world > 1)                                 // block-uniform: every thread takes part in the barriers
+    g = xgmi_exchange(a.x, 0, *a.step_dev + a.seq_bias, blockIdx.x, p, ch == 0 && p < a.n, g) * a.grad_scale;
+  if (ch == 0 && p < a.n) {
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.theta != nullptr) {
       const float mn = m0 + (g - m0) * (1.f - a.b1);
@@ -362,9 +370,25 @@ int32_t dmf_backward_dlogits(const dmf_shape* s, const dmf_input* in, const floa
   return run_patch(s, in, MODE_BWD, theta, pool_w, nullptr, dlogits, 1.f, nullptr, nullptr, nullptr, workspace, nullptr, stream);
 }
 
+static int fill_xgmi(const dmf_xgmi_comm* c, XgmiDev& x) {
+  if (c->world < 2 || c->world > XGMI_MAX || c->rank < 0 || c->rank >= c->world) return fail("%s", "bad xgmi world/rank");
+  if (c->capacity <= 0) return fail("%s", "bad xgmi capacity");
+  x.world = c->world; x.rank = c->rank;
+  x.cap = (c->capacity + 255) / 256 * 256;
+  x.nblk = xgmi_nblk(x.cap);
+  x.timeout_ticks = (int64_t)(c->timeout_ms > 0 ? c->timeout_ms : 20000) * 100000;   // wall_clock64 runs at 100 MHz
+  for (int r = 0; r < c->world; ++r) {
+    if (c->data[r] == nullptr || c->flags[r] == nullptr) return fail("%s", "xgmi peer buffer missing");
+    x.data[r] = static_cast<float*>(c->data[r]);
+    x.flags[r] = static_cast<int32_t*>(c->flags[r]);
+  }
+  return 0;
+}
+
 static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, float* theta, float* m,
                       float* v, float lr, float b1, float b2, float eps, int32_t step, const int32_t* step_dev,
-                      int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream) {
+                      int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream,
+                      const dmf_xgmi_comm* comm = nullptr, float grad_scale = 1.f) {
   if (s == nullptr || workspace == nullptr) return fail("%s", "null argument");
   if (B <= 0) return fail("%s", "batch must be positive");
   const Layout L = layout_of(*s);
@@ -384,6 +408,13 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
     }
   }
   a.step_dev = step_dev; a.cursor_dev = cursor_dev; a.loss = loss; a.loss_hist = loss_hist;
+  a.grad_scale = grad_scale;
+  if (comm != nullptr) {
+    if (step_dev == nullptr) return fail("%s", "the xgmi exchange needs adam_step_dev");
+    if (comm->capacity < L.n_params) return fail("%s", "xgmi communicator smaller than the parameter vector");
+    if (fill_xgmi(comm, a.x)) return 1;
+    a.seq_bias = comm->seq_bias;
+  }
   const int grid = (int)((L.n_params + 15) / 16) + 1;   // + the bookkeeping block
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return check(hipGetLastError(), "grad_reduce launch");
@@ -401,6 +432,83 @@ int32_t dmf_grad_reduce_adam(const dmf_shape* s, int32_t B, const void* workspac
   if (theta == nullptr) return fail("%s", "null theta");
   return run_reduce(s, B, workspace, grad, theta, m, v, lr, beta1, beta2, eps, step, adam_step_dev, cursor_dev, loss,
                     loss_hist, stream);
+}
+
+int32_t dmf_grad_reduce_xgmi_adam(const dmf_shape* s, int32_t B, const void* workspace, float* theta, float* m,
+                                  float* v, const dmf_xgmi_comm* comm, float lr, float beta1, float beta2, float eps,
+                                  float grad_scale, const int32_t* adam_step_dev, int32_t* cursor_dev,
+                                  const float* loss, float* loss_hist, void* stream) {
+  if (theta == nullptr || comm == nullptr) return fail("%s", "null theta/comm");
+  return run_reduce(s, B, workspace, nullptr, theta, m, v, lr, beta1, beta2, eps, 0, adam_step_dev, cursor_dev, loss,
+                    loss_hist, stream, comm, grad_scale);
+}
+
+// ------------------------------------------------------------------------------ xgmi buffers + small all-reduce
+int32_t dmf_xgmi_sizes(int64_t capacity, int32_t world, int64_t* data_bytes, int64_t* flag_bytes) {
+  if (capacity <= 0 || world < 1 || world > XGMI_MAX || data_bytes == nullptr || flag_bytes == nullptr)
+    return fail("%s", "bad xgmi_sizes argument");
+  const int64_t cap = (capacity + 255) / 256 * 256;
+  *data_bytes = 4 * cap * (int64_t)sizeof(float);
+  *flag_bytes = (xgmi_status_index(world, xgmi_nblk(cap)) + 16) * (int64_t)sizeof(int32_t);
+  return 0;
+}
+
+int32_t dmf_xgmi_alloc(int64_t bytes, void** ptr) {
+  if (bytes <= 0 || ptr == nullptr) return fail("%s", "bad xgmi_alloc argument");
+  void* p = nullptr;
+  if (check(hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached), "hipExtMallocWithFlags(uncached)")) return 1;
+  if (check(hipMemset(p, 0, (size_t)bytes), "hipMemset") || check(hipDeviceSynchronize(), "hipDeviceSynchronize")) {
+    (void)hipFree(p);
+    return 1;
+  }
+  *ptr = p;
+  return 0;
+}
+
+int32_t dmf_xgmi_free(void* ptr) { return ptr == nullptr ? 0 : check(hipFree(ptr), "hipFree"); }
+
+int32_t dmf_xgmi_export(void* ptr, uint8_t handle[64]) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+  if (ptr == nullptr || handle == nullptr) return fail("%s", "null argument");
+  hipIpcMemHandle_t h;
+  if (check(hipIpcGetMemHandle(&h, ptr), "hipIpcGetMemHandle")) return 1;
+  memcpy(handle, &h, 64);
+  return 0;
+}
+
+int32_t dmf_xgmi_open(const uint8_t handle[64], void** ptr) {
+  if (ptr == nullptr || handle == nullptr) return fail("%s", "null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, 64);
+  return check(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+}
+
+int32_t dmf_xgmi_close(void* ptr) { return ptr == nullptr ? 0 : check(hipIpcCloseMemHandle(ptr), "hipIpcCloseMemHandle"); }
+
+int32_t dmf_xgmi_status(const dmf_xgmi_comm* c, int32_t* status) {
+  if (c == nullptr || status == nullptr) return fail("%s", "null argument");
+  XgmiDev x{};
+  if (fill_xgmi(c, x)) return 1;
+  if (check(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 1;
+  return check(hipMemcpy(status, x.flags[x.rank] + xgmi_status_index(x.world, x.nblk), sizeof(int32_t), hipMemcpyDeviceToHost),
+               "hipMemcpy(status)");
+}
+
+__global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgmiDev x, float* buf, int64_t n, int seq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < n;
+  const float s = xgmi_exchange(x, 1, seq, blockIdx.x, i, valid, valid ? buf[i] : 0.f);
+  if (valid) buf[i] = s;
+}
+
+int32_t dmf_xgmi_allreduce(const dmf_xgmi_comm* c, float* buf, int64_t n, int32_t seq, void* stream) {
+  if (c == nullptr || buf == nullptr) return fail("%s", "null argument");
+  XgmiDev x{};
+  if (fill_xgmi(c, x)) return 1;
+  if (n <= 0 || n > x.cap || seq < 1) return fail("%s", "xgmi_allreduce: n must be in [1, capacity], seq >= 1");
+  hipLaunchKernelGGL(xgmi_allreduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, buf, n, seq);
+  return check(hipGetLastError(), "xgmi_allreduce launch");
 }
 
 int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,

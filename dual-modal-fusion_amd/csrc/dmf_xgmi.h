@@ -1,0 +1,72 @@
+// dmf_xgmi.h — device side of the one-shot gradient exchange over xGMI (include/dmf.h "dmf_xgmi_*").
+//
+// Memory layout (per rank, both allocated uncached so that remote writes/reads never sit in a local L2):
+//   data  : [region 2][parity 2][cap] float      region 0 = training exchange, 1 = dmf_xgmi_allreduce
+//   flags : [region 2][src rank world][nblk] int32, then one status word
+// Protocol for block `blk` at sequence number `seq` (monotonic, identical on all ranks):
+//   1. publish own values in data[rank][region][seq&1]                      (system-scope stores)
+//   2. flags[peer][region][rank][blk] = seq on every peer                   (release, system scope)
+//   3. wait until flags[rank][region][peer][blk] >= seq for every peer      (acquire, bounded by a wall-clock timeout)
+//   4. read data[r][region][seq&1] for r = 0..world-1 and add in that order
+// A peer can run at most one sequence number ahead (it needs this rank's flag to finish the next one), which is
+// what the two parities are for.  Blocks never wait for other blocks of the same grid.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmf {
+
+constexpr int XGMI_MAX = 16;
+
+struct XgmiDev {
+  int world, rank;
+  int64_t cap;
+  int nblk;
+  int64_t timeout_ticks;            // wall_clock64 ticks (100 MHz)
+  float* data[XGMI_MAX];
+  int32_t* flags[XGMI_MAX];
+};
+
+__host__ __device__ inline int xgmi_nblk(int64_t cap) { return (int)((cap + 15) / 16); }
+__host__ __device__ inline int64_t xgmi_status_index(int world, int nblk) { return (int64_t)2 * world * nblk; }
+
+// All 256 threads of the block call this (it contains block barriers).  Returns the rank-ordered sum for
+// threads with valid == true.
+__device__ __forceinline__ float xgmi_exchange(const XgmiDev& x, int region, int seq, int blk, int64_t idx,
+                                               bool valid, float g) {
+  const int tid = threadIdx.x;
+  const int64_t slot = ((int64_t)(region * 2 + (seq & 1))) * x.cap + idx;
+  if (valid) __hip_atomic_store(x.data[x.rank] + slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (tid < x.world && tid != x.rank) {
+    __hip_atomic_store(x.flags[tid] + ((int64_t)(region * x.world + x.rank)) * x.nblk + blk, seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    int32_t* mine = x.flags[x.rank] + ((int64_t)(region * x.world + tid)) * x.nblk + blk;
+    int32_t* status = x.flags[x.rank] + xgmi_status_index(x.world, x.nblk);
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+      const uint64_t t0 = wall_clock64();
+      while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
+          __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float s = 0.f;
+  if (valid) {
+    float v[XGMI_MAX];
+#pragma unroll
+    for (int r = 0; r < XGMI_MAX; ++r)
+      v[r] = (r < x.world) ? __hip_atomic_load(x.data[r] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+#pragma unroll
+    for (int r = 0; r < XGMI_MAX; ++r)
+      if (r < x.world) s += v[r];
+  }
+  return s;
+}
+
+}  // namespace dmf

@@ -9,8 +9,10 @@ What it removes from the reference's hot loop (solver/mainsolver.py:49-58):
   * per-launch host work                                   -> an epoch plan (shuffled coordinates + labels) is
     uploaded once and a captured hipGraph of `steps_per_graph` steps is replayed; batch cursor and the
     Adam step count live in device memory.
-Data parallel (world_size > 1): `dmf_grad_reduce` -> all-reduce(sum) of ONE flat fp32 gradient over RCCL ->
-`dmf_adam_step(grad_scale = 1/world_size)`; identical updates on every rank.
+Data parallel (world_size > 1), two forms with identical updates on every rank:
+  * with a `dmf.xgmi.Communicator`: `dmf_grad_reduce_xgmi_adam` — the ranks exchange their flat gradient inside the
+    reduce + Adam launch (one-shot over xGMI, rank-ordered sum), still two launches per step and graph-replayable;
+  * without: `dmf_grad_reduce` -> all-reduce(sum) of ONE flat fp32 gradient over RCCL -> `dmf_adam_step(1/world)`.
 """
 import numpy as np
 import torch
@@ -32,7 +34,7 @@ class Scene:
 
 
 class TrainEngine:
-    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm=None):
         self.net, self.scene, self.B = net, scene, int(batch)
         self.shape = net.shape
         lib.shape_supported(self.shape)
@@ -54,6 +56,9 @@ class TrainEngine:
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+        self.comm = comm if self.world > 1 else None
+        if self.comm is not None and (self.comm.world != self.world or self.comm.capacity < self.theta.numel()):
+            raise lib.DmfError('xgmi communicator does not match this engine (world / capacity)')
         # device-side bookkeeping for graph replay
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -78,12 +83,18 @@ class TrainEngine:
         self.step_count += 1
         theta = self.theta
         nB = inp.B
+        if self.comm is not None and dev_step is None:   # the exchange numbers its rounds by the device step count
+            dev_step = self.dev_step
         lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
                           adam_step_dev=dev_step)
         if self.world == 1:
             lib.grad_reduce_adam(self.shape, nB, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
                                  self.step_count, adam_step_dev=dev_step, cursor_dev=dev_cursor,
                                  loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
+        elif self.comm is not None:
+            lib.grad_reduce_xgmi_adam(self.shape, nB, self.ws, theta, self.m, self.v, self.comm.c, self.lr, self.b1,
+                                      self.b2, self.eps, 1.0 / self.world, dev_step, cursor_dev=dev_cursor,
+                                      loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
         else:
             import torch.distributed as dist
             lib.grad_reduce(self.shape, nB, self.ws, self.grad)
@@ -123,10 +134,10 @@ class TrainEngine:
 
     def run_plan(self, steps=None, steps_per_graph=0):
         """Run `steps` steps of the loaded plan (default: all).  steps_per_graph > 0 replays a captured hipGraph
-        (single-GPU only); 0 launches eagerly.  No host synchronisation."""
+        (single GPU, or data parallel over the xgmi communicator); 0 launches eagerly.  No host synchronisation."""
         steps = self.plan_steps if steps is None else steps
         done = 0
-        if steps_per_graph > 0 and self.world == 1:
+        if steps_per_graph > 0 and (self.world == 1 or self.comm is not None):
             if self.graph is None or self.graph_steps != steps_per_graph:
                 self._capture(steps_per_graph)
             while steps - done >= steps_per_graph:
@@ -138,19 +149,23 @@ class TrainEngine:
         return steps
 
     def _capture(self, n):
-        # one eager warm-up step on a side stream state copy is not needed: the kernels were already launched
-        # (hipFuncSetAttribute is not capturable), so make sure of that first
+        # hipFuncSetAttribute is not capturable, so every kernel must have been launched once before the capture:
+        # run one step eagerly, then put back the exact pre-step state (capture itself executes nothing).
+        state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
         count0 = self.step_count
-        saved = [t.clone() for t in (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)]
+        saved = [t.clone() for t in state]
         self._plan_step()
+        torch.cuda.synchronize()
+        for t, s in zip(state, saved):
+            t.copy_(s)
+        self.step_count = count0
+        if self.comm is not None:                  # the eager step used up an exchange sequence number; the bias is
+            self.comm.rewind(1)                    # a launch argument, so it has to move BEFORE the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for _ in range(n):
                 self._plan_step()
-        # capture executed nothing, the warm-up did: restore the exact pre-capture state
-        for t, s in zip((self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist), saved):
-            t.copy_(s)
         self.step_count = count0
         self.graph, self.graph_steps = g, n
 

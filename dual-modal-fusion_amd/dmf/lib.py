@@ -21,6 +21,11 @@ class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('C', 'C2', 'P', 'S', 'F', 'G', 'H', 'K', 'attention', 'heads', 'E', 'reserved')]
 
 
+class XgmiComm(C.Structure):
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('capacity', C.c_int64), ('timeout_ms', C.c_int32),
+                ('seq_bias', C.c_int32), ('data', C.c_void_p * 16), ('flags', C.c_void_p * 16)]
+
+
 class Input(C.Structure):
     _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('a', C.c_void_p), ('b', C.c_void_p), ('sceneA', C.c_void_p),
                 ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32), ('cursor', C.c_void_p)]
@@ -47,6 +52,16 @@ def _load():
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
         'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp]),
         'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
+        'dmf_xgmi_sizes': (i32, [i64, i32, C.POINTER(i64), C.POINTER(i64)]),
+        'dmf_xgmi_alloc': (i32, [i64, C.POINTER(vp)]),
+        'dmf_xgmi_free': (i32, [vp]),
+        'dmf_xgmi_export': (i32, [vp, C.c_char_p]),
+        'dmf_xgmi_open': (i32, [C.c_char_p, C.POINTER(vp)]),
+        'dmf_xgmi_close': (i32, [vp]),
+        'dmf_xgmi_status': (i32, [C.POINTER(XgmiComm), C.POINTER(i32)]),
+        'dmf_xgmi_allreduce': (i32, [C.POINTER(XgmiComm), vp, i64, i32, vp]),
+        'dmf_grad_reduce_xgmi_adam': (i32, [SP, i32, vp, vp, vp, vp, C.POINTER(XgmiComm), f32, f32, f32, f32, f32, vp, vp,
+                                            vp, vp, vp]),
         'dmf_confusion_accum': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_labelmap_write': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_pan2ms': (i32, [vp, i32, i32, i32, vp, vp]),
@@ -175,6 +190,56 @@ def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step, ada
     check(_lib.dmf_grad_reduce_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), _ptr(grad),
                                     lr, b1, b2, eps, step, _ptr(adam_step_dev), _ptr(cursor_dev), _ptr(loss),
                                     _ptr(loss_hist), _stream()))
+
+
+def grad_reduce_xgmi_adam(shape, B, ws, theta, m, v, comm, lr, b1, b2, eps, grad_scale, adam_step_dev, cursor_dev=None,
+                          loss=None, loss_hist=None):
+    check(_lib.dmf_grad_reduce_xgmi_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), C.byref(comm), lr, b1,
+                                         b2, eps, grad_scale, _ptr(adam_step_dev), _ptr(cursor_dev), _ptr(loss),
+                                         _ptr(loss_hist), _stream()))
+
+
+def xgmi_sizes(capacity, world):
+    d, f = C.c_int64(), C.c_int64()
+    check(_lib.dmf_xgmi_sizes(capacity, world, C.byref(d), C.byref(f)))
+    return d.value, f.value
+
+
+def xgmi_alloc(nbytes):
+    p = C.c_void_p()
+    check(_lib.dmf_xgmi_alloc(nbytes, C.byref(p)))
+    return p.value
+
+
+def xgmi_free(ptr):
+    check(_lib.dmf_xgmi_free(C.c_void_p(ptr)))
+
+
+def xgmi_export(ptr):
+    h = C.create_string_buffer(64)
+    check(_lib.dmf_xgmi_export(C.c_void_p(ptr), h))
+    return h.raw
+
+
+def xgmi_open(handle):
+    p = C.c_void_p()
+    check(_lib.dmf_xgmi_open(C.create_string_buffer(handle, 64), C.byref(p)))
+    return p.value
+
+
+def xgmi_close(ptr):
+    check(_lib.dmf_xgmi_close(C.c_void_p(ptr)))
+
+
+def xgmi_status(comm):
+    st = C.c_int32()
+    check(_lib.dmf_xgmi_status(C.byref(comm), C.byref(st)))
+    return st.value
+
+
+def xgmi_allreduce(comm, buf, n, seq):
+    _dev(buf, torch.float32, 'buf')
+    check(_lib.dmf_xgmi_allreduce(C.byref(comm), _ptr(buf), n, seq, _stream()))
 
 
 def confusion_accum(pred, target, K, matrix):

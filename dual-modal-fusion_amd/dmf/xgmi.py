@@ -1,0 +1,104 @@
+"""One-shot gradient exchange between the per-GPU processes of a node (include/dmf.h "dmf_xgmi_*").
+
+Each rank owns two uncached device buffers (published gradients, arrival flags) and maps every peer's pair
+through HIP IPC; the 64-byte handles travel over the torch.distributed group that already exists for the job.
+`create()` verifies the mapping with a known-answer all-reduce against the group's own all_reduce before the
+communicator is handed out; if any rank cannot set it up (IPC refused, a wait timed out, a sum differs) every
+rank gets None and the caller stays on the RCCL all-reduce path.
+"""
+import sys
+
+import torch
+import torch.distributed as dist
+
+from . import lib
+
+
+class Communicator:
+    def __init__(self, capacity, group=None, timeout_ms=20000):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if not 2 <= self.world <= 16:
+            raise lib.DmfError('xgmi exchange is built for 2..16 ranks, got %d' % self.world)
+        self.capacity = int(capacity)
+        self._own, self._mapped = [], []
+        data_bytes, flag_bytes = lib.xgmi_sizes(self.capacity, self.world)
+        data = lib.xgmi_alloc(data_bytes); self._own.append(data)
+        flags = lib.xgmi_alloc(flag_bytes); self._own.append(flags)
+        mine = (lib.xgmi_export(data), lib.xgmi_export(flags))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        self.c = lib.XgmiComm(world=self.world, rank=self.rank, capacity=self.capacity, timeout_ms=int(timeout_ms),
+                              seq_bias=0)
+        for r, (hd, hf) in enumerate(handles):
+            if r == self.rank:
+                self.c.data[r], self.c.flags[r] = data, flags
+            else:
+                pd = lib.xgmi_open(hd); self._mapped.append(pd)
+                pf = lib.xgmi_open(hf); self._mapped.append(pf)
+                self.c.data[r], self.c.flags[r] = pd, pf
+        self._seq = 0
+
+    def allreduce_(self, buf):
+        """In-place sum over ranks (rank order) of a contiguous fp32 device tensor with numel <= capacity."""
+        self._seq += 1
+        lib.xgmi_allreduce(self.c, buf, buf.numel(), self._seq)
+        return buf
+
+    def rewind(self, steps):
+        """The host moved the device step count back by `steps` (graph warm-up): keep sequence numbers rising."""
+        self.c.seq_bias += int(steps)
+
+    def status(self):
+        """0 = every wait so far was satisfied; 1 = a rank gave up waiting (host sync)."""
+        return lib.xgmi_status(self.c)
+
+    def close(self):
+        torch.cuda.synchronize()
+        for p in self._mapped:
+            lib.xgmi_close(p)
+        for p in self._own:
+            lib.xgmi_free(p)
+        self._mapped, self._own = [], []
+
+
+def _all_agree(ok, group, device):
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
+def create(capacity, group=None, timeout_ms=20000, verbose=True):
+    """Build a communicator and prove it with two known-answer exchanges; None (on every rank) if that fails."""
+    backend = dist.get_backend(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    comm, err = None, ''
+    try:
+        comm = Communicator(capacity, group, timeout_ms=min(timeout_ms, 5000))
+    except Exception as e:                      # noqa: BLE001 — any failure means "use RCCL", reported below
+        err = '%s: %s' % (type(e).__name__, e)
+    ok = _all_agree(comm is not None, group, dev)
+    if ok:
+        world, rank = comm.world, comm.rank
+        n = min(comm.capacity, 4096)
+        for rnd in range(2):                    # two rounds: both parities of the publish buffer
+            buf = (torch.arange(n, dtype=torch.float32, device='cuda') % 97) * (rank + 1) + rnd
+            want = (torch.arange(n, dtype=torch.float32, device='cuda') % 97) * (world * (world + 1) // 2) + rnd * world
+            comm.allreduce_(buf)
+            good = comm.status() == 0 and torch.equal(buf, want)
+            ok = _all_agree(good, group, dev) and ok
+            if not good:
+                err = err or 'known-answer exchange failed (status %d)' % comm.status()
+        comm.c.timeout_ms = int(timeout_ms)
+    if not ok:
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:                   # noqa: BLE001
+                pass
+        if verbose:
+            print('[dmf.xgmi] rank %d: one-shot exchange unavailable (%s); using the RCCL all-reduce'
+                  % (dist.get_rank(group), err or 'a peer failed'), file=sys.stderr, flush=True)
+        return None
+    return comm

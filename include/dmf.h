@@ -127,6 +127,42 @@ int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* work
 /* loss / loss_hist (may be NULL): when both are given, loss_hist[cursor] = mean(loss[0..B)) (fixed-order sum),
  * i.e. the value the reference prints per step (`loss.item()`, mainsolver.py:58) without a host sync. */
 
+/* ---- data-parallel gradient exchange over xGMI ------------------------------------
+ * The reference has no multi-GPU path (BaseSolver builds one loader on one device, basesolver.py:86-105); the
+ * coupling between data-parallel ranks is the parameter update of mainsolver.py:54-55 only.  One-shot exchange
+ * for the sub-MB gradient: every rank publishes its local gradient in its own uncached device buffer, raises a
+ * per-block flag on every peer, and each rank then reads all published gradients over xGMI and adds them in rank
+ * order (same bits on every rank, no atomics), inside the gradient-reduce + Adam launch.  Buffers are shared
+ * between the per-GPU processes with HIP IPC handles; the caller moves the 64-byte handles between ranks (any
+ * host channel: torch.distributed all_gather_object, a file, a pipe).  Everything is device-side, so a whole
+ * data-parallel step can be captured in a hipGraph. */
+#define DMF_XGMI_MAX_RANKS 16
+typedef struct dmf_xgmi_comm {
+  int32_t world, rank;
+  int64_t capacity;       /* floats per exchange this communicator was sized for (>= n_params)             */
+  int32_t timeout_ms;     /* a rank that waits longer for a peer sets status = 1 and stops waiting          */
+  int32_t seq_bias;       /* added to the device step count to form the exchange sequence number; the host  */
+                          /* raises it whenever it rewinds the device step count (graph warm-up)            */
+  void* data[DMF_XGMI_MAX_RANKS];    /* data[r]: rank r's publish buffer (own allocation or IPC mapping)    */
+  void* flags[DMF_XGMI_MAX_RANKS];   /* flags[r]: rank r's flag block                                       */
+} dmf_xgmi_comm;
+int32_t dmf_xgmi_sizes(int64_t capacity, int32_t world, int64_t* data_bytes, int64_t* flag_bytes);
+int32_t dmf_xgmi_alloc(int64_t bytes, void** ptr);          /* uncached device memory, zero-filled (host sync) */
+int32_t dmf_xgmi_free(void* ptr);
+int32_t dmf_xgmi_export(void* ptr, uint8_t handle[64]);     /* hipIpcGetMemHandle                              */
+int32_t dmf_xgmi_open(const uint8_t handle[64], void** ptr);/* hipIpcOpenMemHandle (another process' buffer)   */
+int32_t dmf_xgmi_close(void* ptr);
+int32_t dmf_xgmi_status(const dmf_xgmi_comm* comm, int32_t* status);   /* host sync; 0 ok, 1 a wait timed out   */
+/* buf[0..n) <- sum over ranks in rank order (n <= capacity).  seq: 1, 2, 3 ... per call, same on all ranks. */
+int32_t dmf_xgmi_allreduce(const dmf_xgmi_comm* comm, float* buf, int64_t n, int32_t seq, void* stream);
+/* dmf_grad_reduce + exchange + dmf_adam_step(grad_scale) in one launch: the data-parallel form of
+ * dmf_grad_reduce_adam.  adam_step_dev is required (the sequence number is *adam_step_dev + seq_bias). */
+int32_t dmf_grad_reduce_xgmi_adam(const dmf_shape* shape, int32_t B, const void* workspace,
+                                  float* theta, float* m, float* v, const dmf_xgmi_comm* comm,
+                                  float lr, float beta1, float beta2, float eps, float grad_scale,
+                                  const int32_t* adam_step_dev, int32_t* cursor_dev,
+                                  const float* loss, float* loss_hist, void* stream);
+
 /* Replaces the per-sample `.item()` loop `test_matrix[pred][target] += 1` (mainsolver.py:140-141):
  * matrix [K, K] int64, rows = prediction. */
 int32_t dmf_confusion_accum(const int32_t* pred, const int32_t* target, int32_t B, int32_t K,

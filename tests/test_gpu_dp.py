@@ -1,7 +1,12 @@
 """GPU: the data-parallel engine path (world_size 2).  Two processes share the one GPU of the test box and talk
 over gloo (RCCL refuses two ranks on one device); the code path is the one `bench.py --gpus N` runs over RCCL:
 dmf_grad_reduce -> all-reduce(sum) of ONE flat gradient -> dmf_adam_step(grad_scale = 1/N).  After 3 steps the
-2-rank parameters must equal those of a single process that trains on the concatenated global batches."""
+2-rank parameters must equal those of a single process that trains on the concatenated global batches.
+
+The same check runs over the one-shot xGMI exchange (dmf_grad_reduce_xgmi_adam, HIP-IPC mapped peer buffers): 2
+ranks stepping eagerly and 3 ranks replaying a captured hipGraph of the whole data-parallel step; on the one-GPU
+box the "peers" are processes on the same device, which exercises the IPC mapping, flags, parities and the
+rank-ordered sum, not the xGMI links themselves."""
 import os
 import sys
 
@@ -14,10 +19,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, 'dual-modal-fusion_amd')
 CFG = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [20, 20, 8]}}, 'scale': 1,
        'aux_bands': 1, 'gmf': {'width': 40}}
-B, STEPS = 32, 3
+B, STEPS = 32, 3          # global batch 2*B = 64; xgmi cases: 6 steps of 48 (divisible by 2 and 3)
 
 
-def _problem():
+def _problem(n=2 * B * STEPS):
     sys.path[:0] = [PKG, REPO]
     from dmf import synth
     from function.function import data_padding, data_padding_aux
@@ -25,9 +30,72 @@ def _problem():
     MS = data_padding(primary, CFG, 'ms').astype(np.float32)
     PAN = data_padding_aux(aux, CFG).astype(np.float32)
     rng = np.random.default_rng(0)
-    xy = np.stack([rng.integers(0, 20, 2 * B * STEPS), rng.integers(0, 20, 2 * B * STEPS)], 1).astype(np.int32)
+    xy = np.stack([rng.integers(0, 20, n), rng.integers(0, 20, n)], 1).astype(np.int32)
     lab = np.maximum(label[xy[:, 0], xy[:, 1]].astype(np.int32), 1)
     return MS, PAN, xy, lab
+
+
+def _train_xgmi(rank, world, port, q, graph_steps):
+    """GB = 48 patches per step, 6 steps; world ranks (or one) — returns parameters and per-step local losses."""
+    import torch.distributed as dist
+    MS, PAN, xy, lab = _problem(48 * 6)
+    from dmf import xgmi
+    from dmf.engine import Scene, TrainEngine
+    from dmf.parallel import shard_batch
+    from model.gmfnet import Net
+    GB, NS = 48, 6
+    pg = comm = None
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        pg = dist.group.WORLD
+    torch.manual_seed(0)
+    net = Net(CFG).to('cuda:0')
+    if world > 1:
+        comm = xgmi.create(sum(p.numel() for p in net.parameters()), pg, timeout_ms=8000)
+        assert comm is not None, 'xgmi communicator could not be set up'
+    eng = TrainEngine(net, Scene(MS, PAN, 'cuda:0'), GB // world, lr=1e-2, process_group=pg, comm=comm)
+    gxy, glab = xy[:NS * GB].reshape(NS, GB, 2), lab[:NS * GB].reshape(NS, GB)
+    lo, hi = shard_batch(GB, rank, world)
+    eng.load_plan(gxy[:, lo:hi].reshape(-1, 2), glab[:, lo:hi].reshape(-1))
+    eng.run_plan(NS, graph_steps)
+    torch.cuda.synchronize()
+    if comm is not None:
+        assert comm.status() == 0, 'a rank timed out waiting for a peer'
+    assert eng.step_count == NS
+    if rank == 0:
+        q.put(eng.theta.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        comm.close()
+        dist.destroy_process_group()
+
+
+def _run_ranks(target, world, extra):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() + 7 * world) % 1000
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    [p.start() for p in procs]
+    try:
+        out = q.get(timeout=300)
+    finally:
+        [p.join(120) for p in procs]
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return out
+
+
+@pytest.mark.parametrize('world,graph_steps', [(2, 0), (3, 3)])
+def test_xgmi_exchange_dp_equals_single_rank_global_batch(world, graph_steps):
+    many = _run_ranks(_train_xgmi, world, (graph_steps,))
+    one = _run_ranks(_train_xgmi, 1, (0,))
+    err = np.abs(many - one).max()
+    print('%d-rank xgmi (graph %d) vs 1-rank parameters: max abs diff %.2e' % (world, graph_steps, err))
+    assert err < 2e-5
 
 
 def _train(rank, world, port, q):
