@@ -50,6 +50,16 @@ struct AttnArgs {   // must match dmf_attention.hip
 int attn_shape_supported(const dmf_shape& s);
 hipError_t attn_dispatch(const dmf_shape& s, const AttnArgs& a, hipStream_t st);
 
+struct QuaArgs {   // must match dmf_qua.hip
+  const float* logits; int bs, K;
+  const int32_t* labels; const int32_t* cursor;
+  float alpha, beta, gamma, eps, tao, grad_scale;
+  float* loss; float* loss_hist; float* dlogits;
+};
+hipError_t launch_qua_loss(const QuaArgs& a, hipStream_t st);
+hipError_t launch_pair_argmax(const float* logits, int bs, int K, int32_t* pred, hipStream_t st);
+hipError_t launch_band_mean(const float* x, int layout, int64_t n_img, int64_t n_pix, int C, float* out, hipStream_t st);
+
 #ifdef DMF_STAMPS
 hipError_t set_stamps(unsigned long long* p);
 #endif
@@ -521,6 +531,30 @@ int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      theta, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, adam_step_dev, cursor_dev);
   return check(hipGetLastError(), "adam launch");
+}
+
+int32_t dmf_qua_loss(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
+                     const dmf_qua_params* prm, float grad_scale, float* loss, float* loss_hist, float* dlogits,
+                     void* stream) {
+  if (logits == nullptr || labels == nullptr || prm == nullptr) return fail("%s", "null argument");
+  if (bs <= 0 || K < 2 || K > KMAX) return fail("%s", "qua_loss: bs must be positive and 2 <= K <= DMF_KMAX");
+  QuaArgs a{logits, bs, K, labels, cursor, prm->alpha, prm->beta, prm->gamma, prm->epsilon, prm->tao, grad_scale,
+            loss, loss_hist, dlogits};
+  return check(launch_qua_loss(a, static_cast<hipStream_t>(stream)), "qua_loss launch");
+}
+
+int32_t dmf_pair_argmax(const float* logits, int32_t bs, int32_t K, int32_t* pred, void* stream) {
+  if (logits == nullptr || pred == nullptr) return fail("%s", "null argument");
+  if (bs <= 0) return 0;
+  if (K < 1) return fail("%s", "pair_argmax: K must be positive");
+  return check(launch_pair_argmax(logits, bs, K, pred, static_cast<hipStream_t>(stream)), "pair_argmax launch");
+}
+
+int32_t dmf_band_mean(const float* x, int32_t layout, int64_t n_img, int64_t n_pix, int32_t C, float* out, void* stream) {
+  if (x == nullptr || out == nullptr) return fail("%s", "null argument");
+  if ((layout != 0 && layout != 1) || n_img <= 0 || n_pix <= 0 || C <= 0 || (layout == 0 && n_img != 1))
+    return fail("%s", "bad band_mean geometry");
+  return check(launch_band_mean(x, layout, n_img, n_pix, C, out, static_cast<hipStream_t>(stream)), "band_mean launch");
 }
 
 int32_t dmf_confusion_accum(const int32_t* pred, const int32_t* target, int32_t B, int32_t K, int64_t* matrix, void* stream) {

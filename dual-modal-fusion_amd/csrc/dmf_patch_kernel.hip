@@ -949,6 +949,8 @@ using ShapeHSI224 = Shape<224, 3, 11, 1, 32, 8, 64>;  // BASELINE config 4: 224-
 using ShapePanMs = Shape<4, 1, 16, 4, 40, 1, 64>;     // the reference's own data: 4-band MS + PAN at 4x, patch 16
 using ShapeTiny = Shape<8, 1, 5, 4, 40, 2, 64>;       // small test scene (tests/golden/g9_trajectory.npz)
 using ShapeTiny1 = Shape<8, 1, 5, 1, 40, 2, 64>;      // small test scene, equal resolution
+using ShapeQua = Shape<4, 1, 16, 1, 40, 1, 64>;       // stage 2 of the two-stage path: one 4-band stream + its band mean
+using ShapeQuaTiny = Shape<4, 1, 5, 1, 40, 1, 64>;    // the same on the small test scene
 
 template <class Sh>
 static bool matches(const dmf_shape& s) {
@@ -958,7 +960,7 @@ static bool matches(const dmf_shape& s) {
 int patch_shape_supported(const dmf_shape& s) {
   if (s.K < 1 || s.K > KMAX) return 0;
   return matches<ShapeHSI>(s) || matches<ShapeHSI224>(s) || matches<ShapePanMs>(s) || matches<ShapeTiny>(s) ||
-         matches<ShapeTiny1>(s);
+         matches<ShapeTiny1>(s) || matches<ShapeQua>(s) || matches<ShapeQuaTiny>(s);
 }
 
 hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
@@ -967,6 +969,8 @@ hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStrea
   if (matches<ShapePanMs>(s)) return launch_patch<ShapePanMs>(mode, a, st);
   if (matches<ShapeTiny>(s)) return launch_patch<ShapeTiny>(mode, a, st);
   if (matches<ShapeTiny1>(s)) return launch_patch<ShapeTiny1>(mode, a, st);
+  if (matches<ShapeQua>(s)) return launch_patch<ShapeQua>(mode, a, st);
+  if (matches<ShapeQuaTiny>(s)) return launch_patch<ShapeQuaTiny>(mode, a, st);
   return hipErrorInvalidValue;
 }
 

@@ -3,7 +3,7 @@
 Reference keys consumed: `patch_size`, `Categories_Number`, `DATA_DICT[data_city].size[2]`
 (config.yml:27-28,77-80), `trans.embed_dim` / `trans.num_head` (config.yml:66-73; consumed by nothing in the
 reference).  Keys this build adds: `scale` (aux/primary resolution ratio; the reference hard-codes 4,
-train/dataset.py:166), `aux_bands`, `gmf.{width,groups,hidden,pool_sigma,attention}`.
+train/dataset.py:166), `aux_bands`, `gmf.{width,groups,hidden,pool_sigma,attention,single_input}`.
 """
 import math
 
@@ -28,8 +28,11 @@ def arch_from_cfg(cfg):
     groups = gmf.get('groups', 'auto')
     if groups in ('auto', None, 0):
         groups = auto_groups(C, width)
+    single = int(gmf.get('single_input', 0))     # stage-2 net (tostagesolver.py:274): one input, aux = its band mean
     return dict(
-        C=C, C2=int(cfg.get('aux_bands', 1)), P=int(cfg['patch_size']), S=int(cfg.get('scale', 4)),
+        single_input=single,
+        C=C, C2=1 if single else int(cfg.get('aux_bands', 1)), P=int(cfg['patch_size']),
+        S=1 if single else int(cfg.get('scale', 4)),
         K=int(cfg['Categories_Number']), F=width, G=int(groups), H=int(gmf.get('hidden', 64)),
         sigma=float(gmf.get('pool_sigma', 2.5)), attention=int(gmf.get('attention', 0)),
         heads=int(trans.get('num_head', 3)), E=int(trans.get('embed_dim', 96)),

@@ -221,3 +221,147 @@ class EvalEngine:
             _, pred = self.predict(xy)
             lib.labelmap_write(pred, xy, W, label_map)
         return label_map
+
+
+# ====================================================================== stage 2 of the two-stage path
+class QuaScene:
+    """The four co-registered padded scenes of stage 2 (ms, pan, ms_gan, pan_gan; tostagesolver.py:248-257) resident
+    in HBM as ONE tall pixel-major scene [4*Hp, Wp, C] plus its band mean [4*Hp, Wp, 1] (the single-input net's
+    auxiliary modality).  Stream k's patch at pixel (x, y) is the tall scene's patch at (x + k*Hp, y); a window
+    never crosses into the next stream because every stream carries its own bottom padding."""
+
+    def __init__(self, scenes, device):
+        if len(scenes) != 4 or any(s.shape != scenes[0].shape for s in scenes):
+            raise lib.DmfError('stage 2 wants four scenes of one shape')
+        self.Hp = int(scenes[0].shape[0])
+        tall = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.float32) for s in scenes], axis=0))
+        self.A = torch.from_numpy(tall).to(device)
+        self.B = lib.band_mean_scene(self.A)
+        self.device = torch.device(device)
+
+    def stack_xy(self, xy, streams=4):
+        """[n, 2] pixel coordinates -> [streams*n, 2] coordinates in the tall scene, stream-major like
+        `torch.concat([data1, data2, data3, data4])` (tostagesolver.py:272)."""
+        xy = torch.as_tensor(xy).to(torch.int32)
+        off = torch.zeros_like(xy)
+        out = []
+        for k in range(streams):
+            off[:, 0] = k * self.Hp
+            out.append(xy + off)
+        return torch.cat(out)
+
+
+class QuaTrainEngine:
+    """Stage-2 train step (tostagesolver.py:268-278) on the resident tall scene: forward of the 4*bs stacked patches,
+    `dmf_qua_loss` (value + d/dlogits), `dmf_backward_dlogits`, `dmf_grad_reduce_adam` — four launches, no host sync.
+    The loss couples the whole batch, so it cannot ride inside the per-patch kernel like cross-entropy does."""
+
+    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not net.arch.get('single_input'):
+            raise lib.DmfError('stage 2 needs the single-input net (cfg["gmf"]["single_input"] = 1)')
+        self.net, self.scene, self.bs = net, scene, int(bs)
+        self.shape = net.shape
+        lib.shape_supported(self.shape)
+        self.params = lib.qua_params(dqtl)
+        self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        dev = scene.device
+        self.theta = net.flat_parameters()
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        K = net.arch['K']
+        self.logits = torch.empty(4 * self.bs, K, device=dev)
+        self.dlogits = torch.empty(4 * self.bs, K, device=dev)
+        self.loss = torch.zeros(1, device=dev)
+        self.ws = torch.empty(lib.workspace_bytes(self.shape, 4 * self.bs) // 4, device=dev)
+        self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_count = 0
+        self.plan_xy = self.plan_labels = self.loss_hist = None
+
+    def _step(self, inp, bs, labels, cursor, loss_hist):
+        self.step_count += 1
+        theta = self.theta
+        lib.forward(self.shape, inp, theta, self.net.pool_w, self.logits)
+        lib.qua_loss(self.logits[:4 * bs], bs, labels, self.params, loss=self.loss, dlogits=self.dlogits[:4 * bs],
+                     cursor=cursor, loss_hist=loss_hist)
+        lib.backward_dlogits(self.shape, inp, theta, self.net.pool_w, self.dlogits, self.ws)
+        lib.grad_reduce_adam(self.shape, 4 * bs, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
+                             self.step_count, cursor_dev=cursor)
+
+    def step(self, xy, labels):
+        """One step on the bs pixels `xy` [bs, 2] (host or device ints) with `labels` [bs]."""
+        bs = int(xy.shape[0])
+        if bs > self.bs:
+            raise lib.DmfError('engine was built for batches of at most %d' % self.bs)
+        dev = self.scene.device
+        xy4 = self.scene.stack_xy(torch.as_tensor(xy).cpu()).to(dev).contiguous()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy4.cpu().numpy())
+        lab = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).contiguous()
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy4)
+        self._step(inp, bs, lab, None, None)
+
+    def load_plan(self, xy_all, labels_all):
+        """An epoch of full batches: xy_all [n*bs, 2], labels_all [n*bs]."""
+        dev = self.scene.device
+        xy = torch.as_tensor(xy_all).to(torch.int32).cpu()
+        lab = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
+        if xy.shape[0] % self.bs or xy.shape[0] != lab.shape[0]:
+            raise lib.DmfError('plan length must be a multiple of the batch size')
+        n = xy.shape[0] // self.bs
+        K = self.net.arch['K']
+        if n and (int(lab.min()) < 0 or int(lab.max()) >= K):
+            raise lib.DmfError('label outside [0, %d)' % K)
+        xy4 = torch.cat([self.scene.stack_xy(xy[i * self.bs:(i + 1) * self.bs]) for i in range(n)]) if n else xy
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy4.numpy())
+        self.plan_xy, self.plan_labels = xy4.to(dev).contiguous(), lab
+        self.loss_hist = torch.zeros(max(n, 1), device=dev)
+        self.dev_cursor.zero_()
+        self.plan_steps = n
+        return n
+
+    def run_plan(self, steps=None):
+        steps = self.plan_steps if steps is None else steps
+        for _ in range(steps):
+            inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=4 * self.bs, cursor=self.dev_cursor)
+            self._step(inp, self.bs, self.plan_labels, self.dev_cursor, self.loss_hist)
+        return steps
+
+    def losses(self):
+        return self.loss_hist[:int(self.dev_cursor.item())].cpu()
+
+
+class QuaEvalEngine:
+    """Stage-2 prediction `(out[:bs] + out[bs:2*bs]).softmax(-1).argmax` (tostagesolver.py:337): only the ms and pan
+    streams enter it, so only those two are computed."""
+
+    def __init__(self, net, scene, batch, dqtl=None):
+        self.net, self.scene, self.B = net, scene, int(batch)
+        self.shape = net.shape
+        lib.shape_supported(self.shape)
+        dev = scene.device
+        self.logits = torch.empty(4 * self.B, net.arch['K'], device=dev)
+        self.pred = torch.empty(self.B, dtype=torch.int32, device=dev)
+        self.loss = torch.zeros(1, device=dev)
+        self.params = lib.qua_params(dqtl) if dqtl is not None else None
+
+    def _forward(self, xy, streams):
+        n = int(xy.shape[0])
+        if n > self.B:
+            raise lib.DmfError('batch larger than the engine was built for')
+        dev = self.scene.device
+        xyk = self.scene.stack_xy(torch.as_tensor(xy).cpu(), streams).to(dev).contiguous()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xyk.cpu().numpy())
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xyk)
+        lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits)
+        return n
+
+    def predict(self, xy):
+        n = self._forward(xy, 2)
+        lib.pair_argmax(self.logits, n, self.pred)
+        return self.logits[:2 * n], self.pred[:n]
+
+    def loss_value(self, xy, labels):
+        """qua_loss of a batch without gradients (the validation loop, tostagesolver.py:288-296); device scalar."""
+        n = self._forward(xy, 4)
+        lab = torch.as_tensor(labels).to(device=self.scene.device, dtype=torch.int32).contiguous()
+        lib.qua_loss(self.logits[:4 * n], n, lab, self.params, loss=self.loss)
+        return self.loss

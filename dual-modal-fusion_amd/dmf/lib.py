@@ -26,6 +26,10 @@ class XgmiComm(C.Structure):
                 ('seq_bias', C.c_int32), ('data', C.c_void_p * 16), ('flags', C.c_void_p * 16)]
 
 
+class QuaParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ('alpha', 'beta', 'gamma', 'epsilon', 'tao')]
+
+
 class Input(C.Structure):
     _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('a', C.c_void_p), ('b', C.c_void_p), ('sceneA', C.c_void_p),
                 ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32), ('cursor', C.c_void_p)]
@@ -62,6 +66,9 @@ def _load():
         'dmf_xgmi_allreduce': (i32, [C.POINTER(XgmiComm), vp, i64, i32, vp]),
         'dmf_grad_reduce_xgmi_adam': (i32, [SP, i32, vp, vp, vp, vp, C.POINTER(XgmiComm), f32, f32, f32, f32, f32, vp, vp,
                                             vp, vp, vp]),
+        'dmf_qua_loss': (i32, [vp, i32, i32, vp, vp, C.POINTER(QuaParams), f32, vp, vp, vp, vp]),
+        'dmf_pair_argmax': (i32, [vp, i32, i32, vp, vp]),
+        'dmf_band_mean': (i32, [vp, i32, i64, i64, i32, vp, vp]),
         'dmf_confusion_accum': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_labelmap_write': (i32, [vp, vp, i32, i32, vp, vp]),
         'dmf_pan2ms': (i32, [vp, i32, i32, i32, vp, vp]),
@@ -240,6 +247,50 @@ def xgmi_status(comm):
 def xgmi_allreduce(comm, buf, n, seq):
     _dev(buf, torch.float32, 'buf')
     check(_lib.dmf_xgmi_allreduce(C.byref(comm), _ptr(buf), n, seq, _stream()))
+
+
+def qua_params(dqtl):
+    """cfg['dqtl'] -> QuaParams (train/loss_function.py:21,32,66-68)."""
+    return QuaParams(alpha=dqtl['alpha'], beta=dqtl['beta'], gamma=dqtl['gamma'], epsilon=dqtl['epsilon'], tao=dqtl['tao'])
+
+
+def qua_loss(logits, bs, labels, params, loss=None, dlogits=None, grad_scale=1.0, cursor=None, loss_hist=None):
+    _dev(logits, torch.float32, 'logits'); _dev(labels, torch.int32, 'labels')
+    K = logits.shape[1]
+    if logits.dim() != 2 or logits.shape[0] != 4 * bs:
+        raise DmfError('qua_loss wants logits [4*bs, K]')
+    if cursor is None and labels.numel() < bs:
+        raise DmfError('qua_loss wants one label per sample')
+    if dlogits is not None:
+        _dev(dlogits, torch.float32, 'dlogits')
+        if dlogits.shape != logits.shape:
+            raise DmfError('dlogits must have the shape of logits')
+    check(_lib.dmf_qua_loss(_ptr(logits), bs, K, _ptr(labels), _ptr(cursor), C.byref(params), grad_scale, _ptr(loss),
+                            _ptr(loss_hist), _ptr(dlogits), _stream()))
+
+
+def pair_argmax(logits, bs, pred):
+    _dev(logits, torch.float32, 'logits'); _dev(pred, torch.int32, 'pred')
+    if logits.dim() != 2 or logits.shape[0] < 2 * bs or pred.numel() < bs:
+        raise DmfError('pair_argmax wants logits [>=2*bs, K] and pred [bs]')
+    check(_lib.dmf_pair_argmax(_ptr(logits), bs, logits.shape[1], _ptr(pred), _stream()))
+
+
+def band_mean_scene(scene):
+    """[Hp, Wp, C] resident scene -> [Hp, Wp, 1] band mean."""
+    _dev(scene, torch.float32, 'scene')
+    out = torch.empty(scene.shape[0], scene.shape[1], 1, device=scene.device)
+    check(_lib.dmf_band_mean(_ptr(scene), 0, 1, scene.shape[0] * scene.shape[1], scene.shape[2], _ptr(out), _stream()))
+    return out
+
+
+def band_mean_patches(a):
+    """[B, C, P, P] patches -> [B, 1, P, P] band mean."""
+    _dev(a, torch.float32, 'a')
+    out = torch.empty(a.shape[0], 1, a.shape[2], a.shape[3], device=a.device)
+    if a.shape[0]:
+        check(_lib.dmf_band_mean(_ptr(a), 1, a.shape[0], a.shape[2] * a.shape[3], a.shape[1], _ptr(out), _stream()))
+    return out
 
 
 def confusion_accum(pred, target, K, matrix):

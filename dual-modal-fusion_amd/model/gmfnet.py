@@ -108,13 +108,19 @@ class Net(nn.Module):
         return self._ws[key]
 
     # ---- reference call signature ------------------------------------------------------------------
-    def forward(self, ms, pan):
+    def forward(self, ms, pan=None):
+        """`net(ms, pan)` (mainsolver.py:52); with gmf.single_input also `net(data)` (tostagesolver.py:274)."""
         if not ms.is_cuda:
             raise lib.DmfError('model.gmfnet.Net runs on the GPU only (hand-written HIP kernels); '
                                'set cfg["device"] to "cuda:0"')
+        if pan is None and not self.arch['single_input']:
+            raise TypeError('forward(x) with one input needs cfg["gmf"]["single_input"] = 1')
         lib.shape_supported(self.shape)
         a = ms.contiguous().float()
-        b = pan.contiguous().float()
+        if pan is None:
+            b = lib.band_mean_patches(a)
+        else:
+            b = pan.contiguous().float()
         theta = self.flat_parameters()
         if self.arch['attention']:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -77,13 +77,7 @@ class Solver(BaseSolver):
             self.init_model()
         self.cur_model = self.model.to(self.DEVICE)
         if self.fast:
-            from dmf.engine import EvalEngine, TrainEngine
-            if self.cfg['schedule']['loss'] != 'Criterion':
-                raise ValueError('the fused HIP step implements the Criterion (cross-entropy) loss')
-            lr, betas, eps = adam_hparams(self.cfg)
-            self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'], lr=lr, betas=betas, eps=eps,
-                                      process_group=getattr(self, 'process_group', None))
-            self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
+            self._make_engines()
         self.step_losses = []
         while self.epoch < self.EPOCH:
             self.cur_model.train()
@@ -106,6 +100,15 @@ class Solver(BaseSolver):
             self.epoch += 1
         self.train_time = time.time() - time1
         self.epoch = 0
+
+    def _make_engines(self):
+        from dmf.engine import EvalEngine, TrainEngine
+        if self.cfg['schedule']['loss'] != 'Criterion':
+            raise ValueError('the fused HIP step implements the Criterion (cross-entropy) loss')
+        lr, betas, eps = adam_hparams(self.cfg)
+        self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'], lr=lr, betas=betas, eps=eps,
+                                  process_group=getattr(self, 'process_group', None))
+        self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize']
@@ -173,8 +176,11 @@ class Solver(BaseSolver):
             self.init_model()
             self.cur_model = self.model.to(self.DEVICE)
         if self.fast and getattr(self, 'eval_engine', None) is None:
-            from dmf.engine import EvalEngine
-            self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
+            self._make_eval_engine()
+
+    def _make_eval_engine(self):
+        from dmf.engine import EvalEngine
+        self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
 
     def test(self):
         time1 = time.time()

@@ -59,6 +59,9 @@ class dataset_qua_dqtl(Dataset):
         self.Label, self.x, self.y = xyl[2], xyl[0], xyl[1]
         self.size = cfg['patch_size']
 
+    def index_view(self):
+        return _IndexView(self)
+
     def __getitem__(self, index):
         p = self.size
         x, y = int(np.asarray(self.x[index]).reshape(-1)[0]), int(np.asarray(self.y[index]).reshape(-1)[0])

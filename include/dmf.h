@@ -127,6 +127,24 @@ int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* work
 /* loss / loss_hist (may be NULL): when both are given, loss_hist[cursor] = mean(loss[0..B)) (fixed-order sum),
  * i.e. the value the reference prints per step (`loss.item()`, mainsolver.py:58) without a host sync. */
 
+/* ---- stage 2 of the two-stage path (solver/tostagesolver.py:259-346) ---------------------------------------
+ * The stage-2 net takes ONE input, the four streams (ms, pan, ms_gan, pan_gan) stacked on the batch axis
+ * (`torch.concat([data1..data4])`, tostagesolver.py:272), and is trained with `qua_loss`. */
+typedef struct dmf_qua_params { float alpha, beta, gamma, epsilon, tao; } dmf_qua_params;   /* cfg['dqtl'][...] */
+/* Replaces `self.loss(output, bs, target, cfg)` + the logits part of `loss.backward()` (tostagesolver.py:275-277,
+ * train/loss_function.py:57-76).  logits [4*bs, K]; labels [bs] int32 (the reference passes float class ids);
+ * cursor (may be NULL) as in dmf_input: labels[(*cursor)*bs + i], loss_hist[*cursor].  loss [1] and loss_hist may be
+ * NULL; dlogits [4*bs, K] may be NULL (loss only: the validation loop, tostagesolver.py:293-295) and is multiplied
+ * by grad_scale. */
+int32_t dmf_qua_loss(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
+                     const dmf_qua_params* params, float grad_scale, float* loss, float* loss_hist, float* dlogits,
+                     void* stream);
+/* Replaces `(output[:bs] + output[bs:2*bs]).softmax(dim=-1).data.max(1)[1]` (tostagesolver.py:337,366,378). */
+int32_t dmf_pair_argmax(const float* logits, int32_t bs, int32_t K, int32_t* pred, void* stream);
+/* Auxiliary input of the single-stream net: per-pixel mean over bands, ((x0+x1)+x2)+... then / C.
+ * layout 0: pixel-major scene [n_pix, C] (n_img = 1) -> out [n_pix]; 1: band-major patches [n_img, C, n_pix] -> out [n_img, n_pix]. */
+int32_t dmf_band_mean(const float* x, int32_t layout, int64_t n_img, int64_t n_pix, int32_t C, float* out, void* stream);
+
 /* ---- data-parallel gradient exchange over xGMI ------------------------------------
  * The reference has no multi-GPU path (BaseSolver builds one loader on one device, basesolver.py:86-105); the
  * coupling between data-parallel ranks is the parameter update of mainsolver.py:54-55 only.  One-shot exchange

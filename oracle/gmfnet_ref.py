@@ -21,6 +21,8 @@ Architecture (all fp32, ReLU, no normalisation layers):
             spat_a : depthwise 3x3 conv F -> F, zero pad 1        + ReLU   ("spatial")
   branch B  lift_b : SxS stride-S conv C2 -> F                    + ReLU   (resolution lift)
             spat_b : depthwise 3x3 conv F -> F, zero pad 1        + ReLU
+  single-input form (gmf.single_input = 1, the stage-2 net of tostagesolver.py:274 called as net(x)):
+            a = x, b = mean over the bands of x (C2 = 1, S = 1)
   [optional cross-modal attention: tokens = P*P pixels, E = heads*32;
             Ta' = Ta + (softmax(Q K^T / sqrt(dh)) V) Wo^T,  Q = Ta Wq^T, K = Tb Wk^T, V = Tb Wv^T]
   pooling   z = [sum_pix w[pix] * Ya[:, pix] ; sum_pix w[pix] * Yb[:, pix]]      (fixed anchor-Gaussian w)
@@ -48,8 +50,11 @@ def arch_from_cfg(cfg):
         groups = auto_groups(C, width)
     heads = int(trans.get('num_head', 3))
     embed = int(trans.get('embed_dim', 96))
+    single = int(gmf.get('single_input', 0))     # stage-2 net of the two-stage path: one input, aux = its band mean
     return dict(
-        C=C, C2=int(cfg.get('aux_bands', 1)), P=int(cfg['patch_size']), S=int(cfg.get('scale', 4)),
+        single_input=single,
+        C=C, C2=1 if single else int(cfg.get('aux_bands', 1)), P=int(cfg['patch_size']),
+        S=1 if single else int(cfg.get('scale', 4)),
         K=int(cfg['Categories_Number']), F=width, G=int(groups), H=int(gmf.get('hidden', 64)),
         sigma=float(gmf.get('pool_sigma', 2.5)), attention=int(gmf.get('attention', 0)),
         heads=heads, E=embed, mfma_bf16=int(gmf.get('mfma_bf16', 1)),
@@ -78,6 +83,15 @@ def anchor_pool_weights(P, sigma):
         w = torch.ones(P, P, dtype=torch.float64)
     w = w / w.sum()
     return w.reshape(-1).to(torch.float32)
+
+
+def band_mean(a):
+    """Auxiliary input of the single-input net: per-pixel mean over bands of a [B, C, P, P] batch, summed in band
+    order ((x0 + x1) + x2) + ... and divided by C (the intensity component `I` of image_convert/IHS.py:46)."""
+    s = a[:, 0]
+    for c in range(1, a.shape[1]):
+        s = s + a[:, c]
+    return (s / float(a.shape[1])).unsqueeze(1)
 
 
 def bf16_round(x):
@@ -147,7 +161,12 @@ class Net(nn.Module):
         zb = (yb.reshape(B, Fw, -1) * w).sum(-1)
         return torch.cat([za, zb], dim=1)
 
-    def forward(self, a, b):
+    def forward(self, a, b=None):
+        """`net(ms, pan)` (mainsolver.py:52) or, with gmf.single_input, `net(data)` (tostagesolver.py:274)."""
+        if b is None:
+            if not self.arch['single_input']:
+                raise TypeError('forward(a) with one input needs cfg["gmf"]["single_input"] = 1')
+            b = band_mean(a)
         ya, yb = self.branches(a, b)
         if self.arch['attention']:
             ya = self.attention(ya, yb)

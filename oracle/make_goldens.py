@@ -22,6 +22,12 @@ Fixtures (SURVEY.md §8c list):
   g8_qua_loss.npz         qua_loss value + grad                              (loss_function.py:15-76)
   g9_trajectory.npz       reference Solver.train/test driving the oracle Net (mainsolver.py:40-148),
                           incl. the random_split / shuffle index stream under torch.manual_seed(3407) (G4)
+  g10_stage2.npz          reference toStageSolver.train/test (tostagesolver.py:259-346) driving the oracle Net in
+                          its single-input form over the real dataset_qua_dqtl and the real qua_loss.
+                          solver/tostagesolver.py imports model.generator / model.discriminator (absent from the
+                          reference) and torchvision (absent from the image) at module level: inert placeholders are
+                          registered for them too; stage 1 (the GAN, tostagesolver.py:86-238) is NOT exercised —
+                          its outputs ms_gan / pan_gan are synthetic arrays, as with dqtl.pre_trained = 1
 """
 import json
 import os
@@ -165,6 +171,8 @@ def main():
 
     # ---- G9 (+G4): the real reference Solver.train / Solver.test around the oracle Net
     _trajectory(rf, rds, rk, synth)
+    # ---- G10: the real reference toStageSolver.train / .test (stage 2) around the oracle Net
+    _trajectory_stage2(rf, rds, rk, rihs, synth)
     print('goldens written to', OUT)
 
 
@@ -263,6 +271,117 @@ def _trajectory(rf, rds, rk, synth):
             out['last.' + k] = v.numpy()
         np.savez_compressed(os.path.join(OUT, 'g9_trajectory.npz'), **out)
         print('G9: %d loss calls, kappa %.6f, test n=%d' % (len(losses), kp, int(s.test_matrix.sum())))
+    finally:
+        rms.make_loss = real_make_loss
+        plug.TRACE['enabled'] = False
+        os.chdir(cwd)
+
+
+def _trajectory_stage2(rf, rds, rk, rihs, synth):
+    for name, attrs in (('model.generator', {'Generator': None}), ('model.discriminator', {'Discriminator2': None}),
+                        ('torchvision', {}), ('torchvision.utils', {'save_image': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    from solver import tostagesolver as rts        # reference
+    from solver import mainsolver as rms           # reference
+    from solver.basesolver import BaseSolver as RBase
+    import model.gmfnet as plug                    # oracle/model/gmfnet.py
+    from oracle import datapath_ref as dref
+
+    H, W, C, P, ncls = 20, 20, 4, 5, 4
+    primary, aux, label = synth.make_scene(H, W, C, 1, 4, n_classes=ncls, seed=5)      # 4-band MS + PAN at 4x
+    pan4 = rihs.pan2ms(np.asarray(aux, dtype=np.float64), [H, W, 4])                   # REAL reference (IHS.py:14-19)
+    g = np.random.default_rng(11)
+    ms_gan = primary + 0.15 * g.standard_normal(primary.shape)                         # stand-ins for stage-1 output
+    pan_gan = pan4 + 0.15 * g.standard_normal(pan4.shape)
+    cfg = {
+        'task': 'classification', 'nohup': 0, 'model_name': 'gmfnet', 'time': 1, 'index': 0, 'epoch': 40,
+        'device': 'cpu', 'gpu_mode': False, 'patch_size': P, 'Categories_Number': ncls + 1,
+        'batchsize': 24, 'test_batchsize': 50, 'color_batchsize': 64, 'train_rate': 0.4, 'verify_rate': 0.1,
+        'data_new': 0, 'data_city': 'syn', 'DATA_DICT': {'syn': {'size': [H, W, C], 'color': synth.class_colors(ncls + 1)}},
+        'schedule': {'loss': 'qua_loss', 'optimizer': 'ADAM', 'if_scheduler': 0, 'scheduler': 'ExponentialLR',
+                     'activate': 'Relu', 'lr': 3e-3, 'base_lr': 5e-4},
+        'train': {'index': 1, 'pretrained': 0, 'save_best': True}, 'test': {'index': 1, 'save_matrix': 1},
+        'color': {'index': 0, 'supervised': 1, 'unsupervised': 1},
+        'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1, 'pre_trained': 1},
+        'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0, 'single_input': 1},
+    }
+    tmp = tempfile.mkdtemp(prefix='dmf_g10_')
+    cfg['RESULT_output'] = os.path.join(tmp, 'out') + '/'
+    cfg['RESULT_excel'] = os.path.join(tmp, 'r.xlsx')
+    os.makedirs(cfg['RESULT_output'])
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    real_make_loss = rms.make_loss
+    try:
+        torch.manual_seed(3407)
+        s = rts.toStageSolver.__new__(rts.toStageSolver)
+        s.cfg, s.task, s.TIME, s.time, s.EPOCH, s.epoch, s.DEVICE = cfg, cfg['task'], cfg['time'], cfg['index'], cfg['epoch'], 0, 'cpu'
+        s.num_workers = 0
+        # what train_stage2 (tostagesolver.py:240-257) builds, with the restated padding (cv2 absent)
+        scenes = [dref.data_padding(x, P) for x in (primary, pan4, ms_gan, pan_gan)]
+        xyl, s.matrix_ = rf.split_data_old(label, cfg)                       # REAL reference
+        order = []
+
+        class Rec(rds.dataset_qua_dqtl):                                     # REAL reference dataset
+            def __getitem__(self, i):
+                order.append(int(i))
+                return super().__getitem__(i)
+
+        s.dataset = Rec(scenes[0], scenes[1], scenes[2], scenes[3], xyl, cfg)
+        s.records = {}
+        s.model = s.cur_model = None
+        s.train_time = s.test_time = 0
+        s.matrix = None
+        losses = []
+
+        def rec_make_loss(kind, c):
+            inner = real_make_loss(kind, c)                                  # REAL reference qua_loss
+
+            class RecLoss(torch.nn.Module):
+                def forward(self, out, bs, t, cc):
+                    v = inner(out, bs, t, cc)
+                    losses.append(float(v.item()))
+                    return v
+            return RecLoss()
+
+        rms.make_loss = rec_make_loss              # Solver.init_model resolves make_loss in mainsolver's namespace
+        plug.TRACE.update(enabled=True, init_state=None, logits=[], train_flags=[])
+        RBase.dataloader(s)
+        split = {k: np.array(getattr(s, k).dataset.indices) for k in ('train_loader', 'test_loader', 'valid_loader')}
+        base = np.array(s.matrix_[1])
+        n_before = len(order)
+        rts.toStageSolver.train(s)                 # REAL reference loop (tostagesolver.py:259-313)
+        train_order = np.array(order[n_before:])
+        n_losses_train = len(losses)
+        flags = list(plug.TRACE['train_flags'])
+        best_state = torch.load(cfg['RESULT_output'] + '0_weights.pth')
+        cur = torch.load(cfg['RESULT_output'] + '0_curweights.pth')
+        n_logits_train = len(plug.TRACE['logits'])
+        try:
+            rts.toStageSolver.test(s)              # REAL reference eval (tostagesolver.py:315-346)
+        except TypeError:
+            pass        # indicator -> expo_result -> Workbook placeholder; test_matrix is already set (:345)
+        test_logits = plug.TRACE['logits'][n_logits_train].numpy()
+        aa, oa, kp, _ = rk.aa_oa(s.test_matrix)
+        out = dict(
+            primary=primary, aux=aux, pan4=pan4, ms_gan=ms_gan, pan_gan=pan_gan, label=label,
+            cfg=json.dumps({k: v for k, v in cfg.items() if k not in ('RESULT_output', 'RESULT_excel')}),
+            labelled=base, split_train=split['train_loader'], split_test=split['test_loader'], split_valid=split['valid_loader'],
+            visit_order=train_order, losses=np.array(losses[:n_losses_train]), is_train_call=np.array(flags[:n_logits_train]),
+            test_logits=test_logits, test_matrix=s.test_matrix, kappa=kp, aa=aa, oa=oa,
+        )
+        for k, v in plug.TRACE['init_state'].items():
+            out['init.' + k] = v.numpy()
+        for k, v in best_state.items():
+            out['best.' + k] = v.numpy()
+        for k, v in cur['state_dict'].items():
+            out['last.' + k] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, 'g10_stage2.npz'), **out)
+        print('G10: %d loss calls, kappa %.6f, test n=%d' % (len(losses), kp, int(s.test_matrix.sum())))
     finally:
         rms.make_loss = real_make_loss
         plug.TRACE['enabled'] = False

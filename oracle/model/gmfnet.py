@@ -18,7 +18,7 @@ class Net(_RefNet):
         if TRACE['enabled'] and TRACE['init_state'] is None:
             TRACE['init_state'] = {k: v.detach().clone() for k, v in self.state_dict().items()}
 
-    def forward(self, a, b):
+    def forward(self, a, b=None):
         out = super().forward(a, b)
         if TRACE['enabled']:
             TRACE['logits'].append(out.detach().clone())

@@ -5,8 +5,10 @@ aux/primary resolution ratio generalised from the hard-coded 4 to `S`:
   * batch materialisation  — train/dataset.py:168-185 (slice HWC window, transpose to CHW, float32)
   * train step             — solver/mainsolver.py:49-55 (zero_grad, forward, CE(target.long()), backward, Adam.step)
   * eval                   — solver/mainsolver.py:102-141 (argmax, test_matrix[pred][target] += 1)
-Its equivalence with the REAL reference solver is pinned at S = 4 by tests/golden/g9_trajectory.npz
-(tests/test_golden_trajectory.py).
+  * stage-2 step / eval     — solver/tostagesolver.py:268-278 (concat four streams, one-input net, qua_loss) and
+                              :331-341 (argmax of softmax(out[:bs] + out[bs:2bs]))
+Its equivalence with the REAL reference solvers is pinned by tests/golden/g9_trajectory.npz (Solver, S = 4) and
+tests/golden/g10_stage2.npz (toStageSolver) in tests/test_golden_trajectory.py.
 """
 import numpy as np
 import torch
@@ -56,3 +58,44 @@ def evaluate(net, MS, PAN, xy, labels, K, P, S, batch=300):
             pred = out.data.max(1, keepdim=True)[1]
             m += dref.confusion(pred.numpy(), labels[i:i + batch], K)
     return m, torch.cat(logits_all)
+
+
+# ---------------------------------------------------------------------------------------------- stage 2
+def materialise4(scenes, xy, P):
+    """train/dataset.py:203-221 for a batch, concatenated like tostagesolver.py:272: [4*bs, C, P, P]."""
+    parts = [np.stack([im[x:x + P, y:y + P, :].transpose(2, 0, 1) for x, y in xy]) for im in scenes]
+    return torch.from_numpy(np.ascontiguousarray(np.concatenate(parts))).type(torch.FloatTensor)
+
+
+def qua_train_steps(net, scenes, xy_plan, label_plan, bs, P, dqtl, lr=1e-3, optimizer=None, batches=None):
+    """tostagesolver.py:268-278.  `batches` (optional) = explicit list of index arrays into the plan, else
+    consecutive batches of `bs`."""
+    opt = optimizer or torch.optim.Adam(net.parameters(), lr=lr)
+    net.train()
+    losses = []
+    if batches is None:
+        batches = [np.arange(i, i + bs) for i in range(0, len(xy_plan) - bs + 1, bs)]
+    for idx in batches:
+        data = materialise4(scenes, xy_plan[idx], P)
+        target = torch.from_numpy(np.asarray(label_plan[idx], dtype=np.float32))
+        n = len(idx)
+        opt.zero_grad()
+        out = net(data)
+        loss = dref.qua_loss(out, n, target, dqtl['alpha'], dqtl['beta'], dqtl['gamma'], dqtl['epsilon'], dqtl['tao'])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    return losses, opt
+
+
+def qua_evaluate(net, scenes, xy, labels, K, P, batch=300):
+    """tostagesolver.py:331-341 over all given pixels."""
+    net.eval()
+    m = np.zeros([K, K])
+    with torch.no_grad():
+        for i in range(0, len(xy), batch):
+            n = len(xy[i:i + batch])
+            out = net(materialise4(scenes, xy[i:i + batch], P))
+            pred = (out[:n] + out[n:2 * n]).softmax(dim=-1).data.max(1, keepdim=True)[1]
+            m += dref.confusion(pred.numpy(), labels[i:i + batch], K)
+    return m

@@ -19,6 +19,8 @@ SHAPES = {
     'hsi': (200, 1, 11, 1, 17),
     'hsi224': (224, 3, 11, 1, 17),
     'panms': (4, 1, 16, 4, 12),
+    'qua': (4, 1, 16, 1, 12),        # stage 2 of the two-stage path: one 4-band stream + its band mean
+    'quatiny': (4, 1, 5, 1, 5),
 }
 
 
@@ -72,7 +74,7 @@ def assert_close(got, want, atol, rtol, what):
         np.unravel_index(int(err.argmax()), tuple(err.shape)) if err.dim() else ())
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
 @pytest.mark.parametrize('B', [1, 37, 300])
 def test_forward_patches(name, B):
     if name in ('hsi224', 'panms') and B == 300:
@@ -94,7 +96,7 @@ def _scene(name, H=23, W=19, seed=5):
     return A, Bm
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
 def test_forward_gather_and_pred(name):
     from dmf import lib
     C, C2, P, S, K = SHAPES[name]
@@ -123,7 +125,7 @@ def test_forward_gather_and_pred(name):
     assert torch.equal(pred.cpu().long()[safe], want.argmax(1)[safe])
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
 @pytest.mark.parametrize('B', [3, 64, 300])
 def test_train_fwd_bwd_grads(name, B):
     from dmf import lib

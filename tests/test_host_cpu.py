@@ -103,11 +103,12 @@ def test_kappa_ihs_qualoss_against_goldens(golden_dir):
     assert np.array_equal(pan2ms(g7['pan'], [4, 4, 4]), g7['p2m'])
     assert np.array_equal(pan2ms(g7['pan_r'], [3, 5, 4]), g7['p2m_r'])
     assert np.allclose(IHS_tran(g7['ihs_ms'], g7['ihs_pan'], np.random.default_rng(0)), g7['ihs_pan'], atol=1e-12)
+    # qua_loss is a HIP kernel behind the reference's call signature: it refuses CPU tensors (tests/test_gpu_parity.py
+    # checks it against G8 on the GPU)
     g8 = _g(golden_dir, 'g8_qua_loss.npz')
-    x = torch.from_numpy(g8['logits']).requires_grad_(True)
-    loss = qua_loss()(x, 10, torch.from_numpy(g8['target']), {'dqtl': json.loads(str(g8['cfg']))})
-    loss.backward()
-    assert abs(loss.item() - float(g8['loss'])) < 1e-6 and np.allclose(x.grad.numpy(), g8['grad'], atol=1e-7)
+    from dmf.lib import DmfError
+    with pytest.raises(DmfError):
+        qua_loss()(torch.from_numpy(g8['logits']), 10, torch.from_numpy(g8['target']), {'dqtl': json.loads(str(g8['cfg']))})
 
 
 def test_utils_factories_match_reference_defaults(golden_dir):
