@@ -32,9 +32,11 @@ struct KArgs {   // must match dmf_patch_kernel.hip
   unsigned short* tokA;
   unsigned short* tokB;
   float* zout;
+  const float* dYa;
+  const float* dYb;
   int32_t K;
 };
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3 };
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4 };
 
 struct AttnArgs {   // must match dmf_attention.hip
   const unsigned short* tokA;
@@ -47,6 +49,21 @@ struct AttnArgs {   // must match dmf_attention.hip
   int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
   int32_t B, K;
 };
+struct AttnTrainArgs {   // must match dmf_attention_train.hip
+  const unsigned short* tokA; const unsigned short* tokB;
+  const float* zin;
+  const float* theta; const float* pool;
+  const int32_t* labels; const int32_t* cursor;
+  const float* dlogits;
+  float loss_scale;
+  float* logits; float* loss;
+  float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;
+  float* dYa; float* dYb;
+  float* aslab;
+  int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
+  int32_t B, K;
+};
+hipError_t attn_train_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st);
 int attn_shape_supported(const dmf_shape& s);
 hipError_t attn_dispatch(const dmf_shape& s, const AttnArgs& a, hipStream_t st);
 
@@ -96,6 +113,7 @@ struct ReduceArgs {
   const int32_t* step_dev;            // optional device-side step count (overrides bc1 / bc2_sqrt)
   int32_t* cursor_dev;                // optional epoch-plan cursor to advance
   const float* loss; float* loss_hist;
+  const float* aslab; int nablk, ASLAB; int64_t oAttn;   // attention weights: sum of the attention kernel's slabs
   XgmiDev x;                          // x.world > 1: exchange the gradient with the peer ranks before Adam
   float grad_scale; int seq_bias;
 };
@@ -149,13 +167,16 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
   float th0 = 0.f, m0 = 0.f, v0 = 0.f;
   if (ch == 0 && p < a.n && a.theta != nullptr) { th0 = a.theta[p]; m0 = a.m[p]; v0 = a.v[p]; }
   if (p < a.n) {
-    if (p < a.NCONV) {
-      const int per = (a.nblk + 15) / 16;
-      const int lo = ch * per, hi = min(a.nblk, lo + per);
+    if (p < a.NCONV || p >= a.oAttn) {
+      const bool att = p >= a.oAttn;
+      const float* sl = att ? a.aslab + (p - a.oAttn) : a.slab + p;
+      const int pitch = att ? a.ASLAB : a.SLAB, nb = att ? a.nablk : a.nblk;
+      const int per = (nb + 15) / 16;
+      const int lo = ch * per, hi = min(nb, lo + per);
       for (int b0 = lo; b0 < hi; b0 += 16) {
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (b0 + i < hi) ? a.slab[(size_t)(b0 + i) * a.SLAB + p] : 0.f;
+        for (int i = 0; i < 16; ++i) v[i] = (b0 + i < hi) ? sl[(size_t)(b0 + i) * pitch] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc += v[i];
       }
@@ -360,6 +381,54 @@ int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* t
   return check(attn_dispatch(*s, t, static_cast<hipStream_t>(stream)), "attention kernel launch");
 }
 
+int64_t dmf_attn_train_workspace_bytes(const dmf_shape* s, int32_t B) {
+  if (s == nullptr || B < 0) return -1;
+  // two bf16 token maps + pooled z + the two dense gradient maps [B][F][P*P]
+  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4 + 2 * (int64_t)s->F * s->P * s->P * 4);
+}
+
+int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                               const int32_t* labels, const float* dlogits, float loss_scale, float* logits, float* loss,
+                               void* workspace, void* attn_workspace, int32_t* adam_step_dev, void* stream) {
+  if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || workspace == nullptr ||
+      attn_workspace == nullptr || logits == nullptr)
+    return fail("%s", "null argument");
+  if ((labels == nullptr) == (dlogits == nullptr)) return fail("%s", "give exactly one of labels / dlogits");
+  if (!s->attention) return fail("%s", "dmf_train_attn_fwd_bwd needs shape->attention == 1");
+  if (dmf_shape_supported(s)) return 1;
+  if (!attn_shape_supported(*s)) return fail("%s", "no compiled attention instance for this shape (E = 96, heads = 3, F = 40)");
+  if (in->B <= 0) return in->B == 0 ? 0 : fail("%s", "negative batch");
+  const Layout L = layout_of(*s);
+  const WsLayout w = make_ws(L, in->B);
+  float* ws = static_cast<float*>(workspace);
+  const size_t B = (size_t)in->B;
+  unsigned short* tokA = static_cast<unsigned short*>(attn_workspace);
+  unsigned short* tokB = tokA + B * 128 * 64;
+  float* z = reinterpret_cast<float*>(tokB + B * 128 * 64);
+  float* dYa = z + B * 2 * s->F;
+  float* dYb = dYa + B * s->F * s->P * s->P;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KArgs a{};
+  a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
+  a.tokA = tokA; a.tokB = tokB; a.zout = z;
+  if (check(patch_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
+  AttnTrainArgs t{};
+  t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w;
+  t.labels = labels; t.cursor = in->cursor; t.dlogits = dlogits; t.loss_scale = loss_scale;
+  t.logits = logits; t.loss = loss;
+  t.ws_z = ws + w.z; t.ws_h = ws + w.h; t.ws_dh = ws + w.dh; t.ws_dl = ws + w.dl;
+  t.dYa = dYa; t.dYb = dYb; t.aslab = ws + w.aslab;
+  t.oWq = L.off[12]; t.oWk = L.off[13]; t.oWv = L.off[14]; t.oWo = L.off[15];
+  t.oFc1w = L.off[8]; t.oFc1b = L.off[9]; t.oFc2w = L.off[10]; t.oFc2b = L.off[11];
+  t.B = in->B; t.K = s->K;
+  const int grid = in->B < MAX_BLOCKS ? in->B : MAX_BLOCKS;          // one slab per workgroup, as the conv kernel
+  if (check(attn_train_dispatch(*s, t, grid, st), "attention training kernel launch")) return 1;
+  KArgs d{};
+  d.in = *in; d.theta = theta; d.pool = pool_w; d.K = s->K;
+  d.slab = ws + w.slab; d.dYa = dYa; d.dYb = dYb; d.adam_step = adam_step_dev;
+  return check(patch_dispatch(*s, MODE_DENSE, d, st), "dense conv backward launch");
+}
+
 int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                     float* logits, int32_t* pred, void* stream) {
   if (logits == nullptr) return fail("%s", "null logits");
@@ -408,6 +477,7 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
   a.slab = ws + w.slab; a.z = ws + w.z; a.h = ws + w.h; a.dh = ws + w.dh; a.dl = ws + w.dl;
   a.B = B; a.nblk = B < MAX_BLOCKS ? B : MAX_BLOCKS; a.SLAB = L.SLAB; a.NCONV = L.NCONV; a.F2 = L.F2; a.H = L.H; a.K = L.K;
   a.oFc1w = L.off[8]; a.oFc1b = L.off[9]; a.oFc2w = L.off[10]; a.oFc2b = L.off[11]; a.n = L.n_params;
+  a.aslab = ws + w.aslab; a.nablk = a.nblk; a.ASLAB = 4 * L.E * L.F; a.oAttn = L.attention ? L.off[12] : L.n_params;
   a.grad = grad; a.theta = theta; a.m = m; a.v = v;
   a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps;
   if (theta != nullptr) {

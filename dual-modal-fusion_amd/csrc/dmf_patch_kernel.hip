@@ -32,7 +32,9 @@
 
 namespace dmf {
 
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3 };   // TOKENS: conv stages only, for the attention kernel
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4 };
+// TOKENS: conv stages only, for the attention kernel.  DENSE: conv backward from dense dL/dYa, dL/dYb maps [B][F][P2]
+// (written by the attention kernel's backward) instead of the rank-1 pool x dz form; the head is skipped.
 
 // Diagnostic build only (-DDMF_STAMPS, tools/phase_profile.py): per-phase s_memtime stamps of wave 0, written to a
 // buffer nothing else reads.  The shipped library contains no stamp.
@@ -72,6 +74,8 @@ struct KArgs {
   unsigned short* tokA; // MODE_TOKENS: bf16 token maps [B][128][64] (tokens x channels, zero padded) of both branches
   unsigned short* tokB;
   float* zout;          // MODE_TOKENS: pooled features [B][2F] before attention
+  const float* dYa;     // MODE_DENSE: dL/d(spat_a output) [B][F][P2]
+  const float* dYb;     // MODE_DENSE: dL/d(spat_b output) [B][F][P2]
   int32_t K;
 };
 
@@ -361,9 +365,10 @@ __device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>:
 
 // backward pass 1 of one branch: dW[u][v] += dY2(r,c) * Y1(r+u-1, c+v-1), db += dY2(r,c),
 // with dY2(r,c) = mask(r,c) ? dz * pool[r,c] : 0
-template <class Sh>
+//   (DENSE: dY2(r,c) = mask(r,c) ? dd[r*P + c] : 0, dd = this channel's dense gradient map in global memory)
+template <class Sh, bool DENSE = false>
 __device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh>::RS], uint32_t mr, int f, int r, float dz,
-                                          float dw[9], float& db) {
+                                          float dw[9], float& db, const float* dd = nullptr) {
   using L = Lds<Sh>;
   const float m0 = r > 0 ? 1.f : 0.f, m2 = r < Sh::P - 1 ? 1.f : 0.f;
   const int r0 = r > 0 ? r - 1 : 0, r2 = r < Sh::P - 1 ? r + 1 : Sh::P - 1;
@@ -376,7 +381,7 @@ __device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh
   db = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    const float d2 = ((mr >> c) & 1u) ? dz * pw[c] : 0.f;
+    const float d2 = ((mr >> c) & 1u) ? (DENSE ? dd[r * Sh::P + c] : dz * pw[c]) : 0.f;
     db += d2;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -392,9 +397,9 @@ __device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh
 
 // backward pass 2 of one branch (after the barrier: nobody reads a neighbour's Y1 any more): dY1 of this row, in
 // place.   dY1(r,c) = (Y1(r,c) > 0) * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1);  returns the row in dy[] as well
-template <class Sh>
+template <class Sh, bool DENSE = false>
 __device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const uint32_t* sMk, int f, int r,
-                                          const float w[9], float dz, float dy[Lds<Sh>::RS]) {
+                                          const float w[9], float dz, float dy[Lds<Sh>::RS], const float* dd = nullptr) {
   using L = Lds<Sh>;
   float g[3][L::RS];       // g[u][c] = dY2 at (r+u-1, c); zero outside the patch
 #pragma unroll
@@ -405,7 +410,8 @@ __device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const u
     float pw[L::RS];
     load_row<Sh>(sPool + (in ? rr : r) * L::RS, pw);
 #pragma unroll
-    for (int c = 0; c < Sh::P; ++c) g[u][c] = ((mm >> c) & 1u) ? dz * pw[c] : 0.f;
+    for (int c = 0; c < Sh::P; ++c)
+      g[u][c] = ((mm >> c) & 1u) ? (DENSE ? dd[(in ? rr : r) * Sh::P + c] : dz * pw[c]) : 0.f;
   }
   float y1[L::RS];
   float* row = sY + f * L::FSZ + r * L::RS;
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   const int kst = K < L::W2ROWS ? K : L::W2ROWS;
   for (int i = tid0; i < kst * Sh::H; i += Sh::NT) sW2[i] = th[(unsigned)(Sh::oFc2w + i)];
   for (int i = tid0; i < KMAX; i += Sh::NT) sB2[i] = i < K ? th[(unsigned)(Sh::oFc2w + K * Sh::H + i)] : 0.f;
-  if (MODE == MODE_TRAIN && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
+  if ((MODE == MODE_TRAIN || MODE == MODE_DENSE) && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? a.in.cursor[0] * B : 0;   // epoch-plan offset of this batch
   __syncthreads();
 
@@ -613,9 +619,9 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
     for (int m = 0; m < N1; ++m) {
       const int i = pH + 8 * m;
-      w1r[m] = (jH < Sh::H && i < Sh::F2) ? th[(unsigned)(Sh::oFc1w + jH * Sh::F2 + i)] : 0.f;
+      w1r[m] = (MODE != MODE_DENSE && jH < Sh::H && i < Sh::F2) ? th[(unsigned)(Sh::oFc1w + jH * Sh::F2 + i)] : 0.f;
     }
-    const float b1H = (jH < Sh::H) ? th[(unsigned)(Sh::oFc1b + jH)] : 0.f;
+    const float b1H = (MODE != MODE_DENSE && jH < Sh::H) ? th[(unsigned)(Sh::oFc1b + jH)] : 0.f;
     // From here to the head every wave works on the 4 channels it has just produced (lanes = 4 channels x 16 rows):
     // no workgroup barrier, only the wave's own LDS ordering.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -667,6 +673,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     }
 
     // ------------------------------------------------------------------ P3: head
+    if constexpr (MODE != MODE_DENSE) {
     {   // fc1 + ReLU, all waves: thread (jH, pH) holds W1[jH][pH + 8m]
       float acc = 0.f;
 #pragma unroll
@@ -756,12 +763,16 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     }
     LDS_BARRIER();
     STAMP(5);
+    }   // MODE != MODE_DENSE
 
     // ------------------------------------------------------------------ P4: depthwise backward
     OPAQUE(tid);
     fS = tid >> 4; rS = tid & 15;
     float dza = 0.f, dzb = 0.f;
-    if (spat) {   // dz[f] = ordered sum of the head waves' partials
+    constexpr bool DN = (MODE == MODE_DENSE);
+    const float* dda = DN ? a.dYa + ((size_t)b * Sh::F + fSc) * Sh::P2 : nullptr;
+    const float* ddb = DN ? a.dYb + ((size_t)b * Sh::F + fSc) * Sh::P2 : nullptr;
+    if (!DN && spat) {   // dz[f] = ordered sum of the head waves' partials
 #pragma unroll
       for (int w = 0; w < L::NWH; ++w) { dza += sTmp[w * TMPW + fS]; dzb += sTmp[w * TMPW + Sh::F + fS]; }
     }
@@ -771,8 +782,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       if (act) {
         float pw[L::RS];
         load_row<Sh>(sPool + rS * L::RS, pw);
-        row_bwd_w<Sh>(sY1a, pw, sMaskA[fS * L::MS + rS], fS, rS, dza, dwa, dba);
-        row_bwd_w<Sh>(sY1b, pw, sMaskB[fS * L::MS + rS], fS, rS, dzb, dwb, dbb);
+        row_bwd_w<Sh, DN>(sY1a, pw, sMaskA[fS * L::MS + rS], fS, rS, dza, dwa, dba, dda);
+        row_bwd_w<Sh, DN>(sY1b, pw, sMaskB[fS * L::MS + rS], fS, rS, dzb, dwb, dbb, ddb);
       } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) { dwa[k] = 0.f; dwb[k] = 0.f; }
@@ -804,8 +815,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       for (int q = 0; q < Sh::TB; ++q) dwl[q] = 0.f;
       if (spat && rS < Sh::P) {
         float dya[L::RS], dyb[L::RS];
-        row_bwd_x<Sh>(sY1a, sPool, sMaskA, fS, rS, wA, dza, dya);
-        row_bwd_x<Sh>(sY1b, sPool, sMaskB, fS, rS, wB, dzb, dyb);
+        row_bwd_x<Sh, DN>(sY1a, sPool, sMaskA, fS, rS, wA, dza, dya, dda);
+        row_bwd_x<Sh, DN>(sY1b, sPool, sMaskB, fS, rS, wB, dzb, dyb, ddb);
 #pragma unroll
         for (int c = 0; c < Sh::P; ++c) {
           ga += dya[c];
@@ -910,7 +921,7 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
   using L = Lds<Sh>;
   const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
   hipError_t e = hipSuccess;
-  static bool attr_done[4] = {false, false, false, false};
+  static bool attr_done[5] = {false, false, false, false, false};
   auto set_attr = [&](const void* fn, int m) {
     if (!attr_done[m]) {
       e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
@@ -933,6 +944,15 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
       set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_TOKENS>), 3);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL((patch_kernel<Sh, MODE_TOKENS>), dim3(grid), dim3(Sh::NT), L::BYTES, st, a);
+      break;
+    case MODE_DENSE:
+      if constexpr (Sh::P2 <= 128 && Sh::S == 1 && Sh::F == 40) {      // the shapes the attention kernel is built for
+        set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_DENSE>), 4);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((patch_kernel<Sh, MODE_DENSE>), dim3(grid), dim3(Sh::NT), L::BYTES, st, a);
+      } else {
+        return hipErrorInvalidValue;
+      }
       break;
     default:
       set_attr(reinterpret_cast<const void*>(&patch_kernel<Sh, MODE_BWD>), 2);

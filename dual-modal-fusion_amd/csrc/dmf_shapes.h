@@ -74,7 +74,8 @@ inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int 
 }
 
 // workspace layout (floats): [slab MAX_BLOCKS x SLAB][z B x 2F][h B x H][dh B x H][dl B x KMAX]
-struct WsLayout { int64_t slab, z, h, dh, dl, total; };
+//                            [attention: aslab MAX_BLOCKS x 4EF — per-workgroup gradients of Wq, Wk, Wv, Wo]
+struct WsLayout { int64_t slab, z, h, dh, dl, aslab, total; };
 inline WsLayout make_ws(const Layout& L, int B) {
   WsLayout w{};
   int64_t o = 0;
@@ -83,6 +84,7 @@ inline WsLayout make_ws(const Layout& L, int B) {
   w.h = o;    o += (int64_t)B * L.H;
   w.dh = o;   o += (int64_t)B * L.H;
   w.dl = o;   o += (int64_t)B * KMAX;
+  w.aslab = o; o += L.attention ? (int64_t)MAX_BLOCKS * 4 * L.E * L.F : 0;
   w.total = o;
   return w;
 }

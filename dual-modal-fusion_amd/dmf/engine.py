@@ -4,7 +4,8 @@ What it removes from the reference's hot loop (solver/mainsolver.py:49-58):
   * per-item host patch slicing + 3 H2D copies per step  -> padded scenes live in HBM, patches are
     gathered on-device from pixel coordinates (`dmf_input` mode 1);
   * forward / CE / backward / Adam as separate framework ops -> two launches per step
-    (`dmf_train_fwd_bwd`, `dmf_grad_reduce_adam`);
+    (`dmf_train_fwd_bwd`, `dmf_grad_reduce_adam`; with `gmf.attention` four: token kernel, attention fwd+bwd kernel,
+    conv backward, reduce+Adam — `dmf_train_attn_fwd_bwd`);
   * `loss.item()` every step                               -> per-step mean loss kept on the device;
   * per-launch host work                                   -> an epoch plan (shuffled coordinates + labels) is
     uploaded once and a captured hipGraph of `steps_per_graph` steps is replayed; batch cursor and the
@@ -50,6 +51,9 @@ class TrainEngine:
         self.logits = torch.empty(self.B, K, device=dev)
         self.loss = torch.zeros(self.B, device=dev)
         self.ws = torch.empty(lib.workspace_bytes(self.shape, self.B) // 4, device=dev)
+        self.attn_ws = None
+        if self.shape.attention:                      # token maps + dense gradient maps of the attention block
+            self.attn_ws = torch.empty(lib.attn_train_workspace_bytes(self.shape, self.B), dtype=torch.uint8, device=dev)
         self.step_count = 0
         self.pg = process_group
         self.world = 1
@@ -85,8 +89,12 @@ class TrainEngine:
         nB = inp.B
         if self.comm is not None and dev_step is None:   # the exchange numbers its rounds by the device step count
             dev_step = self.dev_step
-        lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
-                          adam_step_dev=dev_step)
+        if self.shape.attention:
+            lib.train_attn_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, None, 1.0 / nB, self.logits, self.loss,
+                                   self.ws, self.attn_ws, adam_step_dev=dev_step)
+        else:
+            lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
+                              adam_step_dev=dev_step)
         if self.world == 1:
             lib.grad_reduce_adam(self.shape, nB, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
                                  self.step_count, adam_step_dev=dev_step, cursor_dev=dev_cursor,

@@ -52,6 +52,8 @@ def _load():
         'dmf_attn_workspace_bytes': (i64, [SP, i32]),
         'dmf_forward_attn': (i32, [SP, IP, vp, vp, vp, vp, vp, vp]),
         'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
+        'dmf_attn_train_workspace_bytes': (i64, [SP, i32]),
+        'dmf_train_attn_fwd_bwd': (i32, [SP, IP, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
         'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
         'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp]),
@@ -177,6 +179,20 @@ def forward_attn(shape, inp, theta, pool_w, ws, logits, pred=None):
 def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, adam_step_dev=None):
     check(_lib.dmf_train_fwd_bwd(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels),
                                  C.c_float(loss_scale), _ptr(logits), _ptr(loss), _ptr(ws), _ptr(adam_step_dev), _stream()))
+
+
+def attn_train_workspace_bytes(shape, B):
+    n = _lib.dmf_attn_train_workspace_bytes(C.byref(shape), B)
+    if n < 0:
+        raise DmfError('dmf_attn_train_workspace_bytes failed')
+    return n
+
+
+def train_attn_fwd_bwd(shape, inp, theta, pool_w, labels, dlogits, loss_scale, logits, loss, ws, attn_ws,
+                       adam_step_dev=None):
+    check(_lib.dmf_train_attn_fwd_bwd(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels), _ptr(dlogits),
+                                      loss_scale, _ptr(logits), _ptr(loss), _ptr(ws), _ptr(attn_ws), _ptr(adam_step_dev),
+                                      _stream()))
 
 
 def backward_dlogits(shape, inp, theta, pool_w, dlogits, ws):

@@ -47,6 +47,37 @@ class _GmfFunction(torch.autograd.Function):
         return None, None, None, grad
 
 
+class _GmfAttnFunction(torch.autograd.Function):
+    """Attention network.  forward: dmf_forward_attn; backward: dmf_train_attn_fwd_bwd with the caller's dL/dlogits
+    (it recomputes the forward inside the fused fwd+bwd kernels) + dmf_grad_reduce -> one flat gradient."""
+
+    @staticmethod
+    def forward(ctx, net, a, b, theta):
+        inp = lib.input_patches(net.shape, a, b)
+        B = a.shape[0]
+        logits = torch.empty(B, net.arch['K'], device=a.device, dtype=torch.float32)
+        ws = torch.empty(lib.attn_workspace_bytes(net.shape, B), device=a.device, dtype=torch.uint8)
+        lib.forward_attn(net.shape, inp, theta, net.pool_w, ws, logits)
+        ctx.net = net
+        ctx.save_for_backward(a, b, theta)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net = ctx.net
+        a, b, theta = ctx.saved_tensors
+        inp = lib.input_patches(net.shape, a, b)
+        B = a.shape[0]
+        ws = net.workspace(B)
+        attn_ws = torch.empty(lib.attn_train_workspace_bytes(net.shape, B), device=a.device, dtype=torch.uint8)
+        logits = torch.empty(B, net.arch['K'], device=a.device, dtype=torch.float32)
+        lib.train_attn_fwd_bwd(net.shape, inp, theta, net.pool_w, None, dlogits.contiguous().float(), 1.0, logits, None,
+                               ws, attn_ws)
+        grad = torch.empty_like(theta)
+        lib.grad_reduce(net.shape, B, ws, grad)
+        return None, None, None, grad
+
+
 class Net(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -79,9 +110,12 @@ class Net(nn.Module):
             raise lib.DmfError('parameter layout mismatch: torch %d vs library %d' % (n, self._offsets[16]))
 
     # ---- flat parameter vector ------------------------------------------------------------------
+    def _order(self):
+        return PARAM_ORDER + (ATTN_ORDER if self.arch['attention'] else ())
+
     def _named(self):
         d = dict(self.named_parameters())
-        return [d[k] for k in PARAM_ORDER + (ATTN_ORDER if self.arch['attention'] else ())]
+        return [d[k] for k in self._order()]
 
     def flat_parameters(self):
         """One contiguous fp32 vector holding every parameter in the library's order; the nn.Parameters are
@@ -124,8 +158,8 @@ class Net(nn.Module):
         theta = self.flat_parameters()
         if self.arch['attention']:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise lib.DmfError('training with gmf.attention=1 is not built yet: the HIP attention block is forward '
-                                   'only (wrap the call in torch.no_grad())')
+                theta_g = torch.cat([p.reshape(-1) for p in self._named()])
+                return _GmfAttnFunction.apply(self, a, b, theta_g)
             inp = lib.input_patches(self.shape, a, b)
             B = a.shape[0]
             logits = torch.empty(B, self.arch['K'], device=a.device, dtype=torch.float32)

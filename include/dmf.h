@@ -102,6 +102,18 @@ int32_t dmf_train_fwd_bwd(const dmf_shape* shape, const dmf_input* in, const flo
 /* adam_step_dev (may be NULL): device int incremented by one per call (the optimiser step count a later
  * dmf_grad_reduce_adam / dmf_adam_step on the same stream reads instead of its host `step` argument). */
 
+/* The same step for the attention network (shape->attention == 1; BASELINE configs[2]): forward, loss, backward of
+ * head, attention block and conv stages in three launches (token kernel, attention fwd+bwd kernel, conv backward
+ * from dense gradient maps).  Exactly one of labels (fused cross-entropy, as dmf_train_fwd_bwd) and dlogits
+ * (caller-supplied dL/dlogits, as dmf_backward_dlogits; logits are still written) is non-NULL; loss may be NULL.
+ * `workspace` as for dmf_train_fwd_bwd (dmf_workspace_bytes counts the attention slabs when shape->attention),
+ * `attn_workspace` = dmf_attn_train_workspace_bytes(shape, B) bytes.  Gradients leave through dmf_grad_reduce*. */
+int64_t dmf_attn_train_workspace_bytes(const dmf_shape* shape, int32_t B);
+int32_t dmf_train_attn_fwd_bwd(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                               const int32_t* labels, const float* dlogits, float loss_scale,
+                               float* logits, float* loss, void* workspace, void* attn_workspace,
+                               int32_t* adam_step_dev, void* stream);
+
 /* Backward for a caller-supplied dL/dlogits [B, K] (the autograd path: torch computes the loss). */
 int32_t dmf_backward_dlogits(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                              const float* dlogits, void* workspace, void* stream);

@@ -307,5 +307,80 @@ def test_attention_forward(name, B):
     assert no_attn > 5e-4
     err = (got.cpu() - want).abs().max().item()
     print('attention %s B=%d: max|hip - bf16 oracle| = %.2e, |fp32 oracle - bf16 oracle| = %.2e' % (name, B, err, no_attn))
-    with pytest.raises(Exception, match='not built yet'):
-        hip(a.cuda(), b.cuda())                   # grad enabled: training with attention is refused loudly
+
+
+@pytest.mark.parametrize('name', ['tiny1', 'hsi'])
+@pytest.mark.parametrize('B', [2, 70, 300])
+def test_attention_train_grads(name, B):
+    """Fused fwd + CE + bwd of the attention network (token kernel, attention fwd+bwd kernel, dense conv backward,
+    gradient reduce) against torch autograd through the oracle (bf16 forward operands, straight-through roundings).
+    Tolerance: logits as in test_attention_forward; gradients 2e-5 absolute + 2e-3 relative.  Looser than the fp32
+    network's 1e-4 because a bf16 operand on a rounding boundary may round the other way between the two forward
+    passes (accumulation order), which moves the forward value by one bf16 ulp of one operand."""
+    from dmf import lib
+    cfg, ref, hip = _attn_nets(name)
+    a, b, t = rand_batch(name, B)
+    ref.zero_grad()
+    want_logits = ref(a, b)
+    loss = torch.nn.functional.cross_entropy(want_logits, t)
+    loss.backward()
+    K = SHAPES[name][4]
+    ad, bd = a.cuda(), b.cuda()
+    inp = lib.input_patches(hip.shape, ad, bd)
+    theta = hip.flat_parameters()
+    logits = torch.empty(B, K, device='cuda')
+    lossv = torch.empty(B, device='cuda')
+    ws = torch.empty(lib.workspace_bytes(hip.shape, B) // 4, device='cuda')
+    aws = torch.empty(lib.attn_train_workspace_bytes(hip.shape, B), dtype=torch.uint8, device='cuda')
+    lib.train_attn_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t.int().cuda(), None, 1.0 / B, logits, lossv, ws, aws)
+    grad = torch.empty_like(theta)
+    lib.grad_reduce(hip.shape, B, ws, grad)
+    assert_close(logits, want_logits, 2e-4, 0, 'attention train logits[%s,B=%d]' % (name, B))
+    assert abs(lossv.mean().item() - loss.item()) < 2e-4
+    off = hip._offsets
+    worst = 0.0
+    for i, (k, p) in enumerate(zip(hip._order(), hip._named())):
+        want = dict(ref.named_parameters())[k].grad
+        got = grad[off[i]:off[i] + p.numel()].view(p.shape).cpu()
+        err = (got - want).abs().max().item()
+        worst = max(worst, err / (want.abs().max().item() + 1e-12))
+        assert_close(got, want, 2e-5, 2e-3, 'grad %s[%s,B=%d]' % (k, name, B))
+        if k.startswith('attn_'):
+            assert want.abs().max().item() > 1e-6, 'attention gradient vanishes: the test would prove nothing'
+    print('attention train %s B=%d: worst relative-to-max gradient error %.2e' % (name, B, worst))
+
+
+def test_attention_autograd_and_engine_steps():
+    """`net(ms, pan)` + torch loss + backward with attention on (drop-in path), and three fused engine steps against
+    torch Adam on the oracle."""
+    from dmf.engine import Scene, TrainEngine
+    from oracle import solver_ref
+    name = 'tiny1'
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = _attn_nets(name)
+    a, b, t = rand_batch(name, 40)
+    ref.zero_grad()
+    torch.nn.functional.cross_entropy(ref(a, b), t).backward()
+    hip.zero_grad()
+    torch.nn.functional.cross_entropy(hip(a.cuda(), b.cuda()), t.cuda()).backward()
+    for (k, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters()):
+        assert_close(ph.grad, pr.grad, 2e-5, 2e-3, 'autograd grad ' + k)
+    # engine: resident scene, 3 steps of 32 patches, lr 1e-2
+    H, W, Bn = 23, 19, 32
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(8)
+    xy = torch.stack([torch.randint(0, H, (3 * Bn,), generator=g), torch.randint(0, W, (3 * Bn,), generator=g)], 1).int()
+    lab = torch.randint(0, K, (3 * Bn,), generator=g).int()
+    eng = TrainEngine(hip, Scene(A.numpy(), Bm.numpy(), 'cuda:0'), Bn, lr=1e-2)
+    eng.load_plan(xy, lab)
+    eng.run_plan(3, 0)
+    got_losses = eng.mean_losses().numpy()
+    want_losses, _ = solver_ref.train_steps(ref, A.numpy(), Bm.numpy(), xy.numpy(), lab.numpy(), Bn, P, S, lr=1e-2)
+    print('attention engine losses', got_losses, want_losses)
+    assert np.abs(got_losses - np.array(want_losses)).max() < 5e-4
+    # ADAM's first steps move every element by ~lr whatever the size of its gradient, so an element whose gradient is
+    # rounding noise can go either way; the bulk must agree closely, the tail is bounded by steps * lr
+    d = torch.cat([(ph.detach().cpu() - pr.detach()).abs().reshape(-1)
+                   for (_, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters())]).numpy()
+    print('attention engine parameters after 3 steps: 99th percentile diff %.2e, max %.2e' % (np.percentile(d, 99), d.max()))
+    assert np.percentile(d, 99) < 2e-4 and d.max() <= 2 * 3 * 1e-2 + 1e-6
