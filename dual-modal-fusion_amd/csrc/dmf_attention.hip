@@ -1,16 +1,32 @@
-// dmf_attention.hip — cross-modal attention + head, forward (the `gmf.attention: 1` network; BASELINE configs[2]).
+// dmf_attention.hip — cross-modal attention + head of the `gmf.attention: 1` network (BASELINE configs[2]):
+// forward AND backward in one launch for training, and the same forward alone for inference (TRAIN = false).  Sits between two launches of the fused patch kernel:
+//   patch_kernel<MODE_TOKENS>  conv stages -> bf16 token maps Ta, Tb [B][128][64] + pooled z before attention
+//   attn_train_kernel (here)   attention + head forward, CE, head backward, attention backward:
+//                              logits / loss, head vectors for the gradient reduce, attention weight gradients
+//                              (per-workgroup slabs) and the DENSE maps dL/dYa, dL/dYb [B][F][P2]
+//   patch_kernel<MODE_DENSE>   conv backward from those maps
 //
-//   Ta' = Ta + bf16(O) bf16(Wo)^T,   O_h = softmax(bf16(Q_h / sqrt(dh)) bf16(K_h)^T) V_h,
-//   Q = bf16(Ta) bf16(Wq)^T,  K = bf16(Tb) bf16(Wk)^T,  V = bf16(Tb) bf16(Wv)^T           (oracle/gmfnet_ref.py::attention)
-// Tokens are the P*P pixels of a patch (121, padded to 128), E = heads x 32.  Every contraction — the three
-// projections, Q K^T, P V and the output projection — runs on the matrix cores (`v_mfma_f32_16x16x32_bf16`, bf16
-// operands, fp32 accumulate); softmax statistics are fp32, reduced inside the 16-lane MFMA column groups by DPP.
-// Because the network reads the attended map only through the anchor pooling, the kernel never materialises Ta':
-//   za[f] += sum_t w[t] * (bf16(O) bf16(Wo)^T)[t][f],  then fc1 / fc2 / argmax as in the fused patch kernel.
+// Arithmetic (oracle/gmfnet_ref.py::attention, gradients = torch autograd through it): every forward contraction has
+// bf16 operands and fp32 accumulation; the roundings are straight-through, so every backward contraction multiplies a
+// SAVED bf16 operand with an fp32 upstream gradient.  The matrix cores take bf16 only, so an fp32 gradient operand g is
+// fed as hi = bf16(g), lo = bf16(g - hi) in two MFMAs (relative error ~2^-17).
 //
-// One 512-thread workgroup per patch; wave w owns token rows 16w..16w+15 of every product.  All operands live in LDS
-// as bf16 with k contiguous ("NT" form: C[m][n] = sum_k A[m][k] Bn[n][k]) and row strides padded so that the 16-byte
-// fragment reads of a 16-lane group hit 64 distinct banks.
+// What the pooling makes cheap.  The network reads Ta' = Ta + bf16(O) bf16(Wo)^T only through z_a = sum_t w_t Ta'[t],
+// so dTa'[t][f] = w_t dza[f] is rank one and, per head (u = bf16(Wo_h)^T dza, P = softmax, all [T x T] maps stay in
+// registers):
+//   dO = w (x) u                          dWo_h = dza (x) obar_h,    obar_h = sum_t w_t bf16(O_h)[t]
+//   dV = c (x) u,  c = bf16(P)^T w        dWv_h = u (x) bbar,        bbar = bf16(Tb)^T c;     dTb += c (x) (bf16(Wv_h)^T u)
+//   dS[t][j] = w_t P[t][j] (a_j - abar_t),  a = bf16(V) u,  abar = P a            (softmax backward, fp32)
+//   dQs = dS bf16(K),  dK = dS^T bf16(Qs)                                         (MFMA, hi/lo)
+//   dTa += scale dQs bf16(Wq_h),  dTb += dK bf16(Wk_h)                            (MFMA, hi/lo)
+//   dWq_h = scale dQs^T bf16(Ta),  dWk_h = dK^T bf16(Tb)                          (MFMA, hi/lo, k = all 128 tokens)
+//
+// One 512-thread workgroup per patch, wave w owns queries (and, for dK, keys) 16w..16w+15.  Products are formed
+// TRANSPOSED (C[m = key or feature][n = own token]) so that a result in the MFMA C layout — lane holds rows
+// 4*(lane>>4)+r, column lane&15 — is directly the B operand of the next product (n = own token, k = the row index):
+// S^T -> P^T -> O^T -> (O Wo^T)^T and dS^T -> dQs^T -> dTa^T never visit LDS.  Two C tiles i0, i1 give lane group g
+// the k values {16 i0 + 4g + r} U {16 i1 + 4g + r}; the LDS operand is read with the same permutation (frag2).
+// Attention weight gradients accumulate in registers over the workgroup's patches and leave once, as a slab.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -22,34 +38,52 @@ namespace dmf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bfs;   // bf16 storage
+typedef unsigned short bfs;
 
-struct AttnArgs {
-  const bfs* tokA;      // [B][128][64]
-  const bfs* tokB;
-  const float* zin;     // [B][2F] pooled features before attention
-  const float* theta;
-  const float* pool;    // [P*P]
-  float* logits;        // [B][K]
-  int32_t* pred;        // [B] or null
+struct AttnTrainArgs {   // must match dmf_capi.hip
+  const bfs* tokA; const bfs* tokB;     // [B][128][64]
+  const float* zin;                     // [B][2F]
+  const float* theta; const float* pool;
+  const int32_t* labels; const int32_t* cursor;   // labels[(*cursor) * B + b]   (cursor may be null)
+  const float* dlogits;                 // used when labels == null: caller-supplied dL/dlogits [B][K]
+  float loss_scale;
+  float* logits; float* loss;           // [B][K], [B] (loss may be null)
+  float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;   // head vectors for the gradient reduce
+  float* dYa; float* dYb;               // [B][F][P2]
+  float* aslab;                         // [gridDim][4*E*F] attention weight gradients (Wq, Wk, Wv, Wo)
+  int32_t* pred;                        // forward-only launch: argmax per patch (may be null)
+  const bfs* wprep;                     // [NH][WPREP] bf16 weights of every head, already in the LDS layout (attn_prep_kernel)
   int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
   int32_t B, K;
 };
 
-__device__ __forceinline__ bfs f2bf(float x) { return __builtin_bit_cast(bfs, (__bf16)x); }
+// Diagnostic build only (-DDMF_STAMPS, tools/attn_phase_profile.py): clock stamps of wave 0 along one patch.
+#ifdef DMF_STAMPS
+__device__ unsigned long long* g_astamps = nullptr;
+#define ASTAMP() do { if (threadIdx.x == 0 && g_astamps != nullptr && sidx < 64) g_astamps[(size_t)blockIdx.x * 64 + sidx] = clock64(); ++sidx; } while (0)
+#else
+#define ASTAMP() do { } while (0)
+#endif
 
-#define ATT_DPP(v, CTRL, OP) \
+namespace at {
+
+__device__ __forceinline__ bfs f2bf(float x) { return __builtin_bit_cast(bfs, (__bf16)x); }
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+
+#define AT_DPP(v, CTRL, OP) \
   OP((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, true)))
-__device__ __forceinline__ float row16_max(float v) {      // over the 16 lanes sharing lane>>4
-  v = ATT_DPP(v, 0xB1, fmaxf); v = ATT_DPP(v, 0x4E, fmaxf); v = ATT_DPP(v, 0x141, fmaxf); v = ATT_DPP(v, 0x140, fmaxf);
+#define AT_ADD(a, b) ((a) + (b))
+__device__ __forceinline__ float row16_sum(float v) {      // over the 16 lanes sharing lane>>4 (the token index)
+  v = AT_DPP(v, 0xB1, AT_ADD); v = AT_DPP(v, 0x4E, AT_ADD); v = AT_DPP(v, 0x141, AT_ADD); v = AT_DPP(v, 0x140, AT_ADD);
   return v;
 }
-#define ATT_ADD(a, b) ((a) + (b))
-__device__ __forceinline__ float row16_sum(float v) {
-  v = ATT_DPP(v, 0xB1, ATT_ADD); v = ATT_DPP(v, 0x4E, ATT_ADD); v = ATT_DPP(v, 0x141, ATT_ADD); v = ATT_DPP(v, 0x140, ATT_ADD);
-  return v;
+__device__ __forceinline__ float swap16(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)(r[0] ^ r[1] ^ u));   // the value that is not mine
 }
-__device__ __forceinline__ float xrow_sum(float v) {       // over the 4 lanes sharing lane&15 (the four 16-lane rows)
+// reductions over the 4 lanes sharing lane&15 (the four 16-lane groups)
+__device__ __forceinline__ float xrow_sum(float v) {
   {
     const unsigned u = __builtin_bit_cast(unsigned, v);
     auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
@@ -62,252 +96,777 @@ __device__ __forceinline__ float xrow_sum(float v) {       // over the 4 lanes s
   }
   return v;
 }
+__device__ __forceinline__ float xrow_max(float v) {
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  }
+  return v;
+}
 
-// fragment of a k-contiguous bf16 matrix M[row][k] (row stride RS halves): rows r0..r0+15, k0..k0+31
+// standard fragment of a k-contiguous bf16 matrix M[row][k]: rows r0..r0+15, k0 + 8*(lane>>4) .. +7
 template <int RS>
 __device__ __forceinline__ bf16x8 frag(const bfs* M, int r0, int k0, int lane) {
   return *reinterpret_cast<const bf16x8*>(M + (r0 + (lane & 15)) * RS + k0 + 8 * (lane >> 4));
 }
+// permuted fragment pairing with a register operand made of two C tiles: k = kA + 4g + {0..3}, kB + 4g + {0..3}
+template <int RS>
+__device__ __forceinline__ bf16x8 frag2(const bfs* M, int r0, int kA, int kB, int lane) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  const bfs* row = M + (r0 + (lane & 15)) * RS + 4 * (lane >> 4);
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(row + kA);
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + kB);
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// fragment of tokens[t][f] (k = f) gathered from the TRANSPOSED map MT[f][t]: row t = t0 + (lane&15)
+template <int RS>
+__device__ __forceinline__ bf16x8 frag_t(const bfs* MT, int t0, int k0, int lane) {
+  const bfs* p = MT + (k0 + 8 * (lane >> 4)) * RS + t0 + (lane & 15);
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(__bf16, p[i * RS]);
+  return v;
+}
+// register operands from two C tiles
+__device__ __forceinline__ bf16x8 pack_bf(const f32x4& a, const f32x4& b) {
+  return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__device__ __forceinline__ void split_hl(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 ha = (__bf16)a[i], hb = (__bf16)b[i];
+    hi[i] = ha; hi[4 + i] = hb;
+    lo[i] = (__bf16)(a[i] - (float)ha); lo[4 + i] = (__bf16)(b[i] - (float)hb);
+  }
+}
+#define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+// softmax arithmetic: exp(x) = 2^(x * log2 e) on the transcendental unit and a reciprocal instead of 32 divisions per
+// row; both are within ~1e-6 relative of expf / division, far below the bf16 rounding the probabilities get next
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+}  // namespace at
 
 template <class Sh, int E, int NH>
-__global__ __launch_bounds__(512) void attn_head_kernel(const AttnArgs a) {
-  constexpr int T = 128, FP = 64, DH = 32, NT = 512;
-  constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, P2 = Sh::P2;
-  constexpr int FO = (F + 15) / 16 * 16;            // output-projection columns, padded to whole tiles
-  constexpr int NFT = FO / 16;
-  static_assert(E == NH * DH && F <= FP && P2 <= T && H == 64, "attention geometry");
-  // padded row strides (halves): 16-byte reads of 16 consecutive rows must land on distinct bank quads
-  constexpr int TS = 72, KS = 40, VS = 136, WS = 72, OS = 40, PS = 136, QS = 40;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-  bfs* sTa = reinterpret_cast<bfs*>(smraw);         // [T][TS]
-  bfs* sTb = sTa + T * TS;
-  bfs* sK = sTb + T * TS;                           // [T][KS]      K_h
-  bfs* sVt = sK + T * KS;                           // [DH][VS]     V_h transposed
-  bfs* sWq = sVt + DH * VS;                         // [DH][WS]     rows of Wq / Wk / Wv of this head
-  bfs* sWk = sWq + DH * WS;
-  bfs* sWv = sWk + DH * WS;
-  bfs* sWo = sWv + DH * WS;                         // [FO][OS]     Wo[:, head]
-  bfs* sP = sWo + FO * OS;                          // [8 waves][16][PS]
-  bfs* sQ = sP + 8 * 16 * PS;                       // [8 waves][16][QS]  Qs strip, later the O_h strip
-  float* sZ = reinterpret_cast<float*>(sQ + 8 * 16 * QS);   // [F2]
-  float* sHd = sZ + ((F2 + 3) & ~3);                // [H]
-  float* sLg = sHd + H;                             // [KMAX]
-  float* sPw = sLg + KMAX;                          // [T] pooling weights, zero beyond P2
-  float* sDz = sPw + T;                             // [8][FO]
+struct AttnTrainLds {
+  static constexpr int T = 128, FP = 64, DH = 32, FO = 48;
+  static constexpr int VS = 136, QS = 40, KS = 40, WS = 72, OS = 40;
+  // halves
+  static constexpr int oTaT = 0, oTbT = oTaT + FP * VS, oQ = oTbT + FP * VS, oK = oQ + T * QS, oQt = oK + T * KS,
+                       oKt = oQt + DH * VS, oVt = oKt + DH * VS, oWq = oVt + DH * VS, oWk = oWq + DH * WS,
+                       oWv = oWk + DH * WS, oWqT = oWv + DH * WS, oWkT = oWqT + FO * OS, oWo = oWkT + FO * OS,
+                       oDhi = oWo + FO * OS, oDlo = oDhi + DH * VS, HALVES = oDlo + DH * VS;
+  // floats (after the halves)
+  static constexpr int fZ = 0, fHd = fZ + 80, fLg = fHd + 64, fDl = fLg + 64, fDh = fDl + 64, fDz = fDh + 64,
+                       fPw = fDz + 80, fU = fPw + T, fOb = fU + E, fObw = fOb + E, fDzw = fObw + 8 * E,
+                       fSt = fDzw + 8 * FO, fA = fSt + 4 * T, fCw = fA + T, fC = fCw + 8 * T,
+                       fG = fC + T, fBb = fG + FO, FLOATS = fBb + FO;
+  static constexpr int WPREP = 3 * DH * WS + 3 * FO * OS;      // one head's weights: Wq Wk Wv [DH][WS], WqT WkT Wo [FO][OS]
+  static_assert(oWo + FO * OS - oWq == WPREP && WPREP % 8 == 0 && oWq % 8 == 0, "weights are one contiguous LDS block");
+  static constexpr size_t BYTES = (size_t)HALVES * 2 + (size_t)FLOATS * 4;
+  static_assert(HALVES % 8 == 0, "float region stays 16-byte aligned");
+};
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// TRAIN = false: forward only (logits, argmax) — the inference / evaluation kernel of the attention network.
+template <class Sh, int E, int NH, bool TRAIN>
+__global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) {
+  using namespace at;
+  using L = AttnTrainLds<Sh, E, NH>;
+  constexpr int T = L::T, FP = L::FP, DH = L::DH, FO = L::FO, NT = 512;
+  constexpr int VS = L::VS, QS = L::QS, KS = L::KS, WS = L::WS, OS = L::OS;
+  constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, P2 = Sh::P2;
+  static_assert(E == NH * DH && F == 40 && F2 == 80 && H == 64 && P2 <= T, "attention geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  // every LDS array is a constant offset from the dynamic-LDS symbol: no pointer variables that could be spilled as
+  // generic 64-bit pointers (their accesses would become flat_* instead of ds_*)
+#define AT_H(off) (reinterpret_cast<bfs*>(smraw) + (off))
+#define AT_F(off) (reinterpret_cast<float*>(smraw + (size_t)L::HALVES * 2) + (off))
+#define sTaT AT_H(L::oTaT)
+#define sTbT AT_H(L::oTbT)
+#define sQ AT_H(L::oQ)
+#define sK AT_H(L::oK)
+#define sQt AT_H(L::oQt)
+#define sKt AT_H(L::oKt)
+#define sVt AT_H(L::oVt)
+#define sWq AT_H(L::oWq)
+#define sWk AT_H(L::oWk)
+#define sWv AT_H(L::oWv)
+#define sWqT AT_H(L::oWqT)
+#define sWkT AT_H(L::oWkT)
+#define sWo AT_H(L::oWo)
+#define sDhi AT_H(L::oDhi)
+#define sDlo AT_H(L::oDlo)
+#define sZ AT_F(L::fZ)
+#define sHd AT_F(L::fHd)
+#define sLg AT_F(L::fLg)
+#define sDl AT_F(L::fDl)
+#define sDh AT_F(L::fDh)
+#define sDz AT_F(L::fDz)
+#define sPw AT_F(L::fPw)
+#define sU AT_F(L::fU)
+#define sOb AT_F(L::fOb)
+#define sObw AT_F(L::fObw)
+#define sDzw AT_F(L::fDzw)
+#define sSt AT_F(L::fSt)   /* per query t: {row max, w_t / row sum, abar_t, -} */
+#define sA AT_F(L::fA)
+#define sCw AT_F(L::fCw)
+#define sC AT_F(L::fC)
+#define sG AT_F(L::fG)
+#define sBb AT_F(L::fBb)
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int m0 = wave * 16;                          // own queries (and own keys for dK)
   const float* __restrict__ th = a.theta;
   const int K = a.K;
-  const int m0 = wave * 16;                         // this wave's token rows
-  const float scale = 0.17677669529663687f;         // 1/sqrt(32), as float32(1/math.sqrt(32))
+  const float scale = 0.17677669529663687f;          // float32(1/sqrt(32))
+  const int boff = a.cursor != nullptr ? a.cursor[0] * a.B : 0;
 
-  for (int i = tid; i < T; i += NT) sPw[i] = i < P2 ? a.pool[i] : 0.f;
+  for (int i = tid0; i < T; i += NT) sPw[i] = i < P2 ? a.pool[i] : 0.f;
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    // ---- tokens -> LDS (16-byte pieces, rows re-strided to TS)
-    for (int i = tid; i < 2 * T * 8; i += NT) {
-      const int mp = i >> 10, rem = i & 1023, t = rem >> 3, pc = rem & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>((mp ? a.tokB : a.tokA) + ((size_t)b * T + t) * FP + pc * 8);
-      *reinterpret_cast<uint4*>((mp ? sTb : sTa) + t * TS + pc * 8) = v;
+  // attention weight gradients accumulate in this workgroup's slab in global memory (L2 resident); every element has
+  // exactly one owning lane, which adds to it in program order: deterministic, no atomics
+  float* __restrict__ slab = a.aslab + (size_t)blockIdx.x * (4 * E * F);
+  const int wmt = wave / 3, wnt = wave % 3;          // dWq / dWk tile of this wave (waves 0..5): d tile, f tile
+  // head weights this thread needs (forward and backward) are patch invariant: fetched once per workgroup
+  float hw1[10], hw2[8], hwd[8], hwz[11], hwu[8], hb1, hb2;
+  {
+    const int j = tid0 >> 3, pp = tid0 & 7;                        // fc1: row j, columns pp + 8 m;  fc2: row k = j
+#pragma unroll
+    for (int m = 0; m < 10; ++m) hw1[m] = th[a.oFc1w + (int64_t)j * F2 + pp + 8 * m];
+    hb1 = th[a.oFc1b + j];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) hw2[m] = j < K ? th[a.oFc2w + (int64_t)j * H + pp + 8 * m] : 0.f;
+    hb2 = j < K ? th[a.oFc2b + j] : 0.f;
+    const int jd = tid0 & 63, pd = tid0 >> 6;                      // dh: column jd, rows k = pd + 8 i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hwd[i] = (TRAIN && pd + 8 * i < K) ? th[a.oFc2w + (int64_t)(pd + 8 * i) * H + jd] : 0.f;
+    const int pz = tid0 / F2, iz = tid0 - pz * F2;                 // dz: column iz, rows j = pz + 6 m
+#pragma unroll
+    for (int m = 0; m < 11; ++m) hwz[m] = (TRAIN && pz < 6 && pz + 6 * m < H) ? th[a.oFc1w + (int64_t)(pz + 6 * m) * F2 + iz] : 0.f;
+    const int pu = tid0 / E, eu = tid0 - pu * E;                   // u: column eu, rows f = pu + 5 m
+#pragma unroll
+    for (int m = 0; m < 8; ++m) hwu[m] = (TRAIN && pu < 5) ? bf2f((__bf16)th[a.oWo + (int64_t)(pu + 5 * m) * E + eu]) : 0.f;
+  }
+  // first patch's tokens: 4 pieces of 16 bytes per thread, kept in registers and refilled one patch ahead
+  uint4 tokr[4];
+  auto fetch_tokens = [&](int bb, int tid) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + NT * q;
+      const int mp = i >> 10, rem = i & 1023, pc = rem >> 7, t = rem & 127;
+      tokr[q] = *reinterpret_cast<const uint4*>((mp ? a.tokB : a.tokA) + ((size_t)bb * T + t) * FP + pc * 8);
     }
-    if (tid < F2) sZ[tid] = a.zin[(size_t)b * F2 + tid];
-    f32x4 accO[NFT];                                // (O Wo^T)[rows m0.., cols 16n..] accumulated over heads
-#pragma unroll
-    for (int n = 0; n < NFT; ++n) accO[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  if ((int)blockIdx.x < a.B) fetch_tokens(blockIdx.x, tid0);
 
-    for (int h = 0; h < NH; ++h) {
-      __syncthreads();                              // previous head's K/V/weights are no longer read; tokens landed
-      // ---- this head's weight slices, fp32 -> bf16
-      for (int i = tid; i < 3 * DH * FP; i += NT) {
-        const int wsel = i / (DH * FP), rem = i - wsel * (DH * FP), d = rem / FP, f = rem - d * FP;
-        const int64_t o = wsel == 0 ? a.oWq : (wsel == 1 ? a.oWk : a.oWv);
-        const float v = f < F ? th[o + (int64_t)(h * DH + d) * F + f] : 0.f;
-        (wsel == 0 ? sWq : (wsel == 1 ? sWk : sWv))[d * WS + f] = f2bf(v);
-      }
-      for (int i = tid; i < FO * DH; i += NT) {
-        const int f = i / DH, d = i - f * DH;
-        sWo[f * OS + d] = f2bf(f < F ? th[a.oWo + (int64_t)f * E + h * DH + d] : 0.f);
-      }
-      __syncthreads();
-      // ---- projections of this wave's 16 tokens: Q_h, K_h, V_h  = tokens[16 x 64] x W_h^T[64 x 32]
-      {
-        f32x4 q[2], k[2], v[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) { q[n] = k[n] = v[n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < FP / 32; ++ks) {
-          const bf16x8 fa = frag<TS>(sTa, m0, 32 * ks, lane);
-          const bf16x8 fb = frag<TS>(sTb, m0, 32 * ks, lane);
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            q[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, frag<WS>(sWq, 16 * n, 32 * ks, lane), q[n], 0, 0, 0);
-            k[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, frag<WS>(sWk, 16 * n, 32 * ks, lane), k[n], 0, 0, 0);
-            v[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, frag<WS>(sWv, 16 * n, 32 * ks, lane), v[n], 0, 0, 0);
-          }
-        }
-        // C layout: lane holds rows 4*(lane>>4) + r, column lane&15 of each 16x16 tile
-        const int col = lane & 15, rb = 4 * (lane >> 4);
-        bfs* qrow = sQ + wave * 16 * QS;
-#pragma unroll
+  bool first = true;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x, first = false) {
+    // per-thread roles are derived from an opaque copy of the thread id inside the loop: otherwise every index
+    // computation below is loop invariant, gets hoisted in front of the loop and spilled (hundreds of registers)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, g = lane >> 4, col = lane & 15;
+    const int tq = m0 + col;                         // the token this lane's C columns belong to
+    int sidx = 0; (void)sidx;
+    ASTAMP();                                        // 0
+    // stage one head's weights: W[d][f] for the projections; for the backward also W^T[f][d]
+    auto stage_weights = [&](int h, bool bwd, int tid) {
+      (void)bwd;
+      const uint4* src = reinterpret_cast<const uint4*>(a.wprep + (size_t)h * L::WPREP);
+      uint4* dst = reinterpret_cast<uint4*>(sWq);
+      for (int i = tid; i < L::WPREP / 8; i += NT) dst[i] = src[i];
+    };
+    // projections of the wave's 16 tokens; writes Qs (both layouts), K (both layouts), V^T
+    auto project = [&](int lane, int g, int col) {
+      f32x4 q[2], k[2], v[2];
+  #pragma unroll
+      for (int n = 0; n < 2; ++n) q[n] = k[n] = v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+      for (int ks = 0; ks < FP / 32; ++ks) {
+        const bf16x8 fa = frag_t<VS>(sTaT, m0, 32 * ks, lane);
+        const bf16x8 fb = frag_t<VS>(sTbT, m0, 32 * ks, lane);
+  #pragma unroll
         for (int n = 0; n < 2; ++n) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            qrow[(rb + r) * QS + 16 * n + col] = f2bf(q[n][r] * scale);
-            sK[(m0 + rb + r) * KS + 16 * n + col] = f2bf(k[n][r]);
-          }
-          // V transposed: 4 consecutive tokens of one feature -> one 8-byte store
-          const uint2 pk = make_uint2((uint32_t)f2bf(v[n][0]) | ((uint32_t)f2bf(v[n][1]) << 16),
-                                      (uint32_t)f2bf(v[n][2]) | ((uint32_t)f2bf(v[n][3]) << 16));
-          *reinterpret_cast<uint2*>(sVt + (16 * n + col) * VS + m0 + rb) = pk;
+          q[n] = AT_MFMA(fa, frag<WS>(sWq, 16 * n, 32 * ks, lane), q[n]);
+          k[n] = AT_MFMA(fb, frag<WS>(sWk, 16 * n, 32 * ks, lane), k[n]);
+          v[n] = AT_MFMA(fb, frag<WS>(sWv, 16 * n, 32 * ks, lane), v[n]);
         }
       }
-      __syncthreads();                              // K_h, V_h of all 128 tokens are in LDS
-      // ---- S = Qs K^T for this wave's 16 rows x 128 keys, softmax in registers
-      {
-        const bfs* qrow = sQ + wave * 16 * QS;
-        const bf16x8 fq = frag<QS>(qrow, 0, 0, lane);
-        f32x4 s[8];
+      // C layout: rows (tokens) m0 + 4g + r, column (feature) 16n + col
+      const int rb = 4 * g;
+  #pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        bfs qh[4], kh[4], vh[4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qh[r] = f2bf(q[n][r] * scale); kh[r] = f2bf(k[n][r]); vh[r] = f2bf(v[n][r]);
+          sQ[(m0 + rb + r) * QS + 16 * n + col] = qh[r];
+          sK[(m0 + rb + r) * KS + 16 * n + col] = kh[r];
+        }
+        const int o = (16 * n + col) * VS + m0 + rb;     // 4 consecutive tokens of one feature: one 8-byte store
+        *reinterpret_cast<uint2*>(sQt + o) = make_uint2((uint32_t)qh[0] | ((uint32_t)qh[1] << 16), (uint32_t)qh[2] | ((uint32_t)qh[3] << 16));
+        *reinterpret_cast<uint2*>(sKt + o) = make_uint2((uint32_t)kh[0] | ((uint32_t)kh[1] << 16), (uint32_t)kh[2] | ((uint32_t)kh[3] << 16));
+        *reinterpret_cast<uint2*>(sVt + o) = make_uint2((uint32_t)vh[0] | ((uint32_t)vh[1] << 16), (uint32_t)vh[2] | ((uint32_t)vh[3] << 16));
+      }
+    };
+    // P^T for the wave's queries: s[i][r] = P[t = tq][j = 16i + 4g + r]  (fp32, keys >= P2 masked)
+    auto softmax_T = [&](f32x4 (&s)[8], int lane, int g, float& mx_out, float& inv_out) {
+      const bf16x8 fq = frag<QS>(sQ, m0, 0, lane);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, frag<KS>(sK, 16 * j, 0, lane), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const int col = lane & 15, rb = 4 * (lane >> 4);
-        bfs* prow = sP + wave * 16 * PS;
+      for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag<KS>(sK, 16 * i, 0, lane), fq, (f32x4{0.f, 0.f, 0.f, 0.f}));
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float mx = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (16 * j + col >= P2) s[j][r] = -INFINITY;       // padded keys
-            mx = fmaxf(mx, s[j][r]);
-          }
-          mx = row16_max(mx);
-          float sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { s[j][r] = expf(s[j][r] - mx); sum += s[j][r]; }
-          sum = row16_sum(sum);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) prow[(rb + r) * PS + 16 * j + col] = f2bf(s[j][r] / sum);
+          if (16 * i + 4 * g + r >= P2) s[i][r] = -INFINITY;
+          mx = fmaxf(mx, s[i][r]);
         }
+      mx = xrow_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[i][r] = fexp(s[i][r] - mx); sum += s[i][r]; }
+      sum = xrow_sum(sum);
+      const float inv = frcp(sum);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[i][r] *= inv;
+      mx_out = mx; inv_out = inv;
+    };
+    // ------------------------------------------------------------------ tokens -> LDS, transposed [f][t]
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + NT * q;
+      const int mp = i >> 10, rem = i & 1023, pc = rem >> 7, t = rem & 127;
+      const uint4 v = tokr[q];
+      bfs* dst = (mp ? sTbT : sTaT) + (pc * 8) * VS + t;
+      dst[0 * VS] = (bfs)(v.x & 0xffff); dst[1 * VS] = (bfs)(v.x >> 16);
+      dst[2 * VS] = (bfs)(v.y & 0xffff); dst[3 * VS] = (bfs)(v.y >> 16);
+      dst[4 * VS] = (bfs)(v.z & 0xffff); dst[5 * VS] = (bfs)(v.z >> 16);
+      dst[6 * VS] = (bfs)(v.w & 0xffff); dst[7 * VS] = (bfs)(v.w >> 16);
+    }
+    if (b + (int)gridDim.x < a.B) fetch_tokens(b + gridDim.x, tid);      // lands while this patch is processed
+    if (tid < F2) sZ[tid] = a.zin[(size_t)b * F2 + tid];
+
+    // ================================================================== pass 1: forward
+    f32x4 accO[3];                                   // (O Wo^T)^T[f = 16n + 4g + r][t = tq], summed over heads
+#pragma unroll
+    for (int n = 0; n < 3; ++n) accO[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float wq = sPw[tq];                        // (sPw was written before the first barrier of this iteration)
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+      int tidh = tid0;                               // (opaque again: keeps this head's index math inside the loop)
+      asm volatile("" : "+v"(tidh));
+      const int lane = tidh & 63, g = lane >> 4, col = lane & 15;
+      __syncthreads();
+      ASTAMP();                                      // p1: 1 + 4h
+      stage_weights(h, false, tidh);
+      __syncthreads();
+      ASTAMP();
+      project(lane, g, col);
+      __syncthreads();
+      ASTAMP();
+      f32x4 s[8];
+      float mxq, invq;
+      softmax_T(s, lane, g, mxq, invq);
+      ASTAMP();
+      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // O^T[d = 16mt + 4g + r][t = tq]
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 pb = pack_bf(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) o[mt] = AT_MFMA(frag2<VS>(sVt, 16 * mt, 32 * ks, 32 * ks + 16, lane), pb, o[mt]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();              // the P strip and the Q strip are private to this wave
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // ---- O_h = P V (16 x 32), then (O Wo^T) partial
-      {
-        const bfs* prow = sP + wave * 16 * PS;
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const bf16x8 ob = pack_bf(o[0], o[1]);
 #pragma unroll
-        for (int ks = 0; ks < T / 32; ++ks) {
-          const bf16x8 fp = frag<PS>(prow, 0, 32 * ks, lane);
+      for (int n = 0; n < 3; ++n) accO[n] = AT_MFMA(frag2<OS>(sWo, 16 * n, 0, 16, lane), ob, accO[n]);
+      // obar_h[d] = sum_t w_t bf16(O)[t][d]: this wave's 16 tokens
+      if constexpr (TRAIN)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-            o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp, frag<VS>(sVt, 16 * n, 32 * ks, lane), o[n], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = row16_sum(wq * bf2f((__bf16)o[mt][r]));
+          if (col == 0) sObw[wave * E + h * DH + 16 * mt + 4 * g + r] = v;
         }
-        const int col = lane & 15, rb = 4 * (lane >> 4);
-        bfs* orow = sQ + wave * 16 * QS;            // reuse the Q strip (its last reader was this wave's S product)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) orow[(rb + r) * QS + 16 * n + col] = f2bf(o[n][r]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bf16x8 fo = frag<QS>(orow, 0, 0, lane);
-#pragma unroll
-        for (int n = 0; n < NFT; ++n)
-          accO[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fo, frag<OS>(sWo, 16 * n, 0, lane), accO[n], 0, 0, 0);
-      }
     }
-    // ---- pooled correction: dz[f] = sum_t w[t] (O Wo^T)[t][f]
-    {
-      const int col = lane & 15, rb = 4 * (lane >> 4);
+    ASTAMP();                                        // 13
+    // pooled correction za[f] += sum_t w_t (O Wo^T)[t][f]
 #pragma unroll
-      for (int n = 0; n < NFT; ++n) {
-        float p = 0.f;
+    for (int n = 0; n < 3; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p = fmaf(sPw[m0 + rb + r], accO[n][r], p);
-        p = xrow_sum(p);                            // over the four row groups of this wave
-        if (lane < 16) sDz[wave * FO + 16 * n + col] = p;
+      for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(wq * accO[n][r]);
+        if (col == 0) sDzw[wave * FO + 16 * n + 4 * g + r] = v;
       }
-    }
     __syncthreads();
     if (tid < F) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) s += sDz[w * FO + tid];
+      for (int w = 0; w < 8; ++w) s += sDzw[w * FO + tid];
       sZ[tid] += s;
+    } else if (tid >= 64 && tid < 64 + E) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += sObw[w * E + tid - 64];
+      sOb[tid - 64] = s;
     }
     __syncthreads();
-    // ---- head: fc1 + ReLU, fc2, argmax (thread <-> (row j, part p), column p + 8m)
+    // ------------------------------------------------------------------ head forward (weights in registers)
     {
       const int j = tid >> 3, pp = tid & 7;
       float acc = 0.f;
-      for (int i = pp; i < F2; i += 8) acc = fmaf(th[a.oFc1w + (int64_t)j * F2 + i], sZ[i], acc);
-      acc = ATT_DPP(acc, 0xB1, ATT_ADD); acc = ATT_DPP(acc, 0x4E, ATT_ADD); acc = ATT_DPP(acc, 0x141, ATT_ADD);
-      if (pp == 0) sHd[j] = fmaxf(acc + th[a.oFc1b + j], 0.f);
+#pragma unroll
+      for (int m = 0; m < 10; ++m) acc = fmaf(hw1[m], sZ[pp + 8 * m], acc);
+      acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD); acc = AT_DPP(acc, 0x141, AT_ADD);
+      if (pp == 0) sHd[j] = fmaxf(acc + hb1, 0.f);
     }
     __syncthreads();
     {
       const int k = tid >> 3, pp = tid & 7;
       float acc = 0.f;
-      if (k < K)
-        for (int j = pp; j < H; j += 8) acc = fmaf(th[a.oFc2w + (int64_t)k * H + j], sHd[j], acc);
-      acc = ATT_DPP(acc, 0xB1, ATT_ADD); acc = ATT_DPP(acc, 0x4E, ATT_ADD); acc = ATT_DPP(acc, 0x141, ATT_ADD);
-      if (k < K && pp == 0) sLg[k] = acc + th[a.oFc2b + k];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc = fmaf(hw2[m], sHd[pp + 8 * m], acc);
+      acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD); acc = AT_DPP(acc, 0x141, AT_ADD);
+      if (k < K && pp == 0) sLg[k] = acc + hb2;
     }
     __syncthreads();
-    if (wave == 0) {
-      const float v = lane < K ? sLg[lane] : -INFINITY;
-      float mx = v;
+    if constexpr (!TRAIN) {
+      if (wave == 0) {
+        const float v = lane < K ? sLg[lane] : -INFINITY;
+        float mx = v;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      if (lane < K) a.logits[(size_t)b * K + lane] = v;
-      if (a.pred != nullptr) {
-        const unsigned long long bal = __ballot(v == mx);
-        if (lane == 0) a.pred[b] = __ffsll((long long)bal) - 1;
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane < K) a.logits[(size_t)b * K + lane] = v;
+        if (a.pred != nullptr) {
+          const unsigned long long bal = __ballot(v == mx);
+          if (lane == 0) a.pred[b] = __ffsll((long long)bal) - 1;       // first maximal index, as torch.max
+        }
+      }
+      continue;                                      // (the next patch starts with a barrier)
+    }
+    // ------------------------------------------------------------------ loss, dlogits, head backward
+    if (wave == 0) {
+      const float lg = lane < K ? sLg[lane] : -INFINITY;
+      float dl = 0.f;
+      if (a.labels != nullptr) {
+        int label = a.labels[boff + b];
+        label = label < 0 ? 0 : (label >= K ? K - 1 : label);
+        float mx = lg;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = lane < K ? expf(lg - mx) : 0.f;
+        float se = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * a.loss_scale : 0.f;
+        const float lgt = __shfl(lg, label);
+        if (a.loss != nullptr && lane == 0) a.loss[b] = (mx + logf(se)) - lgt;
+      } else {
+        dl = lane < K ? a.dlogits[(size_t)b * K + lane] : 0.f;
+      }
+      if (lane < K) a.logits[(size_t)b * K + lane] = lg;
+      sDl[lane] = dl;
+    }
+    __syncthreads();
+    // head backward.  Every matrix-vector product is split over all 512 threads (partials through LDS, summed in a
+    // fixed order) with its weight loads issued back to back: a 64-term loop in 80 threads costs 64 L2 round trips.
+    {   // dh[j] = relu'(h[j]) sum_k W2[k][j] dl[k]                      thread <-> (j, part of 8)
+      const int j = tid & 63, part = tid >> 6;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int k = part + 8 * i; acc = fmaf(hwd[i], k < K ? sDl[k] : 0.f, acc); }
+      sCw[part * T + j] = acc;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float dh = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dh += sCw[q * T + tid];
+      sDh[tid] = sHd[tid] > 0.f ? dh : 0.f;
+    }
+    __syncthreads();
+    {   // dz[i] = sum_j W1[j][i] dh[j]                                   thread <-> (i, part of 6): j = part + 6 m
+      const int part = tid / F2, i = tid - part * F2;
+      if (part < 6) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 11; ++m) { const int j = part + 6 * m; acc = fmaf(hwz[m], j < H ? sDh[j] : 0.f, acc); }
+        sCw[part * T + i] = acc;
       }
     }
     __syncthreads();
+    if (tid < F2) {
+      float dz = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) dz += sCw[q * T + tid];
+      sDz[tid] = dz;
+      a.ws_z[(size_t)b * F2 + tid] = sZ[tid];
+    } else if (tid >= 128 && tid < 128 + H) {
+      const int j = tid - 128;
+      a.ws_h[(size_t)b * H + j] = sHd[j];
+      a.ws_dh[(size_t)b * H + j] = sDh[j];
+      a.ws_dl[(size_t)b * KMAX + j] = sDl[j];
+    }
+    __syncthreads();
+    {   // u[e] = sum_f dza[f] bf16(Wo[f][e])                             thread <-> (e, part of 5): f = part + 5 m
+      const int part = tid / E, e = tid - part * E;
+      if (part < 5) {
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc = fmaf(sDz[part + 5 * m], hwu[m], acc);
+        sCw[part * T + e] = acc;
+      }
+    }
+    // dWo[f][e] += dza[f] * obar[e]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + NT * i;
+      if (e < F * E) {
+        const float v = sDz[e / E] * sOb[e % E];
+        slab[(size_t)3 * E * F + e] = first ? v : slab[(size_t)3 * E * F + e] + v;
+      }
+    }
+    __syncthreads();
+    if (tid < E) {
+      float u = 0.f;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) u += sCw[q * T + tid];
+      sU[tid] = u;
+    }
+
+    ASTAMP();                                        // 14: head forward + backward done
+    // ================================================================== pass 2: backward, head by head
+    f32x4 accTa[3], accTb[3];                        // dTa^T / dTb^T [f = 16n + 4g + r][token tq]
+#pragma unroll
+    for (int n = 0; n < 3; ++n) accTa[n] = accTb[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+      int tid = tid0;
+      asm volatile("" : "+v"(tid));
+      const int lane = tid & 63, g = lane >> 4, col = lane & 15, tq = m0 + col;
+      __syncthreads();
+      ASTAMP();                                      // p2: 15 + 8h
+      stage_weights(h, true, tid);
+      __syncthreads();
+      ASTAMP();
+      project(lane, g, col);
+      __syncthreads();
+      ASTAMP();
+      // a_j = sum_d bf16(V)[j][d] u_h[d];  g_h[f] = sum_d u_h[d] bf16(Wv_h)[d][f]
+      if (tid < T) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < DH; ++d) s = fmaf(bf2f(__builtin_bit_cast(__bf16, sVt[d * VS + tid])), sU[h * DH + d], s);
+        sA[tid] = s;
+      } else if (tid < T + FO) {
+        const int f = tid - T;
+        float s = 0.f;
+        for (int d = 0; d < DH; ++d) s = fmaf(sU[h * DH + d], bf2f(__builtin_bit_cast(__bf16, sWv[d * WS + f])), s);
+        sG[f] = s;
+      }
+      f32x4 s[8];
+      float mxq, invq;
+      softmax_T(s, lane, g, mxq, invq);              // P[tq][j], j = 16i + 4g + r
+      ASTAMP();
+      __syncthreads();                               // a_j visible
+      {
+        // abar_t = sum_j P[t][j] a_j ;  c_j (this wave's part) = sum_{t own} bf16(P)[t][j] w_t
+        float ab = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ab = fmaf(s[i][r], sA[16 * i + 4 * g + r], ab);
+        ab = xrow_sum(ab);
+        if (g == 0) *reinterpret_cast<float4*>(sSt + 4 * tq) = make_float4(mxq, wq * invq, ab, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float c = row16_sum(wq * bf2f((__bf16)s[i][r]));
+            if (col == 0) sCw[wave * T + 16 * i + 4 * g + r] = c;
+          }
+        // dS^T in place: s[i][r] = w_t P (a_j - abar_t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[i][r] = wq * s[i][r] * (sA[16 * i + 4 * g + r] - ab);
+      }
+      // dQs^T[d][t own] = sum_j K^T[d][j] dS[t][j]
+      f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 hi, lo;
+        split_hl(s[2 * ks], s[2 * ks + 1], hi, lo);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bf16x8 fk = frag2<VS>(sKt, 16 * mt, 32 * ks, 32 * ks + 16, lane);
+          dq[mt] = AT_MFMA(fk, hi, dq[mt]);
+          dq[mt] = AT_MFMA(fk, lo, dq[mt]);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[mt][r] *= scale;
+      {
+        bf16x8 hi, lo;
+        split_hl(dq[0], dq[1], hi, lo);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          const bf16x8 fw = frag2<OS>(sWqT, 16 * n, 0, 16, lane);
+          accTa[n] = AT_MFMA(fw, hi, accTa[n]);
+          accTa[n] = AT_MFMA(fw, lo, accTa[n]);
+        }
+        // dq^T[d][t] -> LDS (hi / lo) for dWq
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = (16 * mt + 4 * g + r) * VS + tq;
+            const __bf16 vh = (__bf16)dq[mt][r];          // (scalars again: extracting hi[4*mt+r] from the packed
+            sDhi[o] = __builtin_bit_cast(bfs, vh);         //  operand vector is folded to element 0 by the compiler)
+            sDlo[o] = __builtin_bit_cast(bfs, (__bf16)(dq[mt][r] - (float)vh));
+          }
+      }
+      ASTAMP();
+      __syncthreads();                               // sync1: dq, softmax statistics, abar, c parts
+      ASTAMP();
+#ifdef DMF_ATT_DEBUG
+      if (h == 0 && b == 0) {
+        float* dbg = a.aslab + (size_t)(4 * E * F);
+        for (int i = tid; i < DH * T; i += NT) {
+          const int d = i / T, t = i % T;
+          dbg[i] = bf2f(__builtin_bit_cast(__bf16, sDhi[d * VS + t]));
+          dbg[DH * T + i] = bf2f(__builtin_bit_cast(__bf16, sTaT[d * VS + t]));
+        }
+        if (wave < 6) {
+          f32x4 tmp = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int ks = 0; ks < 4; ++ks)
+            tmp = AT_MFMA(frag<VS>(sDhi, 16 * wmt, 32 * ks, lane), frag<VS>(sTaT, 16 * wnt, 32 * ks, lane), tmp);
+          for (int r = 0; r < 4; ++r) dbg[2 * DH * T + (wave * 64 + lane) * 4 + r] = tmp[r];
+        }
+      }
+#endif
+      if (tid < T) {
+        float c = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) c += sCw[w * T + tid];
+        sC[tid] = c;
+      }
+      if (wave < 6) {                                // dWq_h tile: [d = 16 wmt ..][f = 16 wnt ..] over all 128 tokens
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 ft = frag<VS>(sTaT, 16 * wnt, 32 * ks, lane);
+          acc = AT_MFMA(frag<VS>(sDhi, 16 * wmt, 32 * ks, lane), ft, acc);
+          acc = AT_MFMA(frag<VS>(sDlo, 16 * wmt, 32 * ks, lane), ft, acc);
+        }
+        if (16 * wnt + col < F) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* p = slab + (size_t)(h * DH + 16 * wmt + 4 * g + r) * F + 16 * wnt + col;
+            *p = first ? acc[r] : *p + acc[r];
+          }
+        }
+      }
+      // S for own KEYS: s[i][r] = S[t = 16i + 4g + r][j = tq]; dS the same way from the owners' statistics
+      f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      {
+        const bf16x8 fk = frag<KS>(sK, m0, 0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag<QS>(sQ, 16 * i, 0, lane), fk, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        const float aj = sA[tq];
+        const bool keyok = tq < P2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float4 st = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r));
+            s[i][r] = keyok ? fexp(s[i][r] - st.x) * st.y * (aj - st.z) : 0.f;      // w_t P[t][j] (a_j - abar_t)
+          }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          bf16x8 hi, lo;
+          split_hl(s[2 * ks], s[2 * ks + 1], hi, lo);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const bf16x8 fq = frag2<VS>(sQt, 16 * mt, 32 * ks, 32 * ks + 16, lane);
+            dk[mt] = AT_MFMA(fq, hi, dk[mt]);
+            dk[mt] = AT_MFMA(fq, lo, dk[mt]);
+          }
+        }
+      }
+      bf16x8 khi, klo;
+      split_hl(dk[0], dk[1], khi, klo);
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const bf16x8 fw = frag2<OS>(sWkT, 16 * n, 0, 16, lane);
+        accTb[n] = AT_MFMA(fw, khi, accTb[n]);
+        accTb[n] = AT_MFMA(fw, klo, accTb[n]);
+      }
+      ASTAMP();
+      __syncthreads();                               // sync2: dWq products have read sD; c is complete
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * mt + 4 * g + r) * VS + tq;
+          const __bf16 vh = (__bf16)dk[mt][r];
+          sDhi[o] = __builtin_bit_cast(bfs, vh);
+          sDlo[o] = __builtin_bit_cast(bfs, (__bf16)(dk[mt][r] - (float)vh));
+        }
+      {                                              // bbar[f] = sum_j c_j bf16(Tb)[j][f]: thread <-> (f, 16 keys)
+        const int f = tid & 63, part = tid >> 6;
+        float s2 = 0.f;
+        if (f < FO) {
+          const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(sTbT + f * VS + 16 * part);
+          const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(sTbT + f * VS + 16 * part + 8);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s2 = fmaf(sC[16 * part + i], bf2f(t0[i]), s2);
+            s2 = fmaf(sC[16 * part + 8 + i], bf2f(t1[i]), s2);
+          }
+        }
+        sCw[part * T + f] = s2;                      // (the c partials in sCw were consumed before sync2)
+      }
+      {                                              // dTb += c (x) g_h
+        const float cj = sC[tq];
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accTb[n][r] = fmaf(cj, sG[16 * n + 4 * g + r], accTb[n][r]);
+      }
+      ASTAMP();
+      __syncthreads();                               // sync3: dK in LDS, bbar partials ready
+      if (wave < 6) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 ft = frag<VS>(sTbT, 16 * wnt, 32 * ks, lane);
+          acc = AT_MFMA(frag<VS>(sDhi, 16 * wmt, 32 * ks, lane), ft, acc);
+          acc = AT_MFMA(frag<VS>(sDlo, 16 * wmt, 32 * ks, lane), ft, acc);
+        }
+        if (16 * wnt + col < F) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* p = slab + (size_t)E * F + (size_t)(h * DH + 16 * wmt + 4 * g + r) * F + 16 * wnt + col;
+            *p = first ? acc[r] : *p + acc[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {                  // dWv_h[d][f] += u_h[d] bbar[f]
+        const int e = tid + NT * i;
+        if (e < DH * F) {
+          float* p = slab + (size_t)2 * E * F + (size_t)h * DH * F + e;
+          const int f = e % F;
+          float bb = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bb += sCw[q * T + f];
+          const float v = sU[h * DH + e / F] * bb;
+          *p = first ? v : *p + v;
+        }
+      }
+    }
+    ASTAMP();                                        // 39
+    // ------------------------------------------------------------------ dense maps for the conv backward
+    if (tq < P2) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * n + 4 * g + r;
+          if (f < F) {
+            a.dYa[((size_t)b * F + f) * P2 + tq] = accTa[n][r] + wq * sDz[f];
+            a.dYb[((size_t)b * F + f) * P2 + tq] = accTb[n][r] + wq * sDz[F + f];
+          }
+        }
+    }
   }
 }
 
-template <class Sh, int E, int NH>
-static size_t attn_lds_bytes() {
-  constexpr int T = 128, DH = 32;
-  constexpr int FO = (Sh::F + 15) / 16 * 16;
-  size_t halves = 2 * T * 72 + T * 40 + DH * 136 + 3 * DH * 72 + FO * 40 + 8 * 16 * 136 + 8 * 16 * 40;
-  size_t floats = ((Sh::F2 + 3) & ~3) + Sh::H + KMAX + T + 8 * FO;
-  return halves * 2 + floats * 4;
+#undef AT_H
+#undef AT_F
+
+// bf16 copies of the attention weights in the LDS layout of attn_train_kernel, one block per head:
+//   [Wq | Wk | Wv : [DH][WS] rows d, k = f]  [WqT | WkT : [FO][OS] rows f, k = d]  [Wo_h : [FO][OS] rows f, k = d]
+template <int E, int NH>
+__global__ __launch_bounds__(256) void attn_prep_kernel(const float* __restrict__ th, int64_t oWq, int64_t oWk, int64_t oWv,
+                                                        int64_t oWo, bfs* __restrict__ out) {
+  using L = AttnTrainLds<Shape<8, 1, 5, 1, 40, 2, 64>, E, NH>;      // the layout does not depend on the patch shape
+  constexpr int F = 40, DH = L::DH, WS = L::WS, FO = L::FO, OS = L::OS;
+  const int h = blockIdx.y;
+  bfs* o = out + (size_t)h * L::WPREP;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L::WPREP; i += gridDim.x * 256) {
+    float v = 0.f;
+    if (i < 3 * DH * WS) {
+      const int w = i / (DH * WS), rem = i - w * (DH * WS), d = rem / WS, f = rem - d * WS;
+      if (f < F) v = th[(w == 0 ? oWq : (w == 1 ? oWk : oWv)) + (int64_t)(h * DH + d) * F + f];
+    } else {
+      const int j = i - 3 * DH * WS, w = j / (FO * OS), rem = j - w * (FO * OS), f = rem / OS, d = rem - f * OS;
+      if (f < F && d < DH)
+        v = w == 2 ? th[oWo + (int64_t)f * E + h * DH + d] : th[(w == 0 ? oWq : oWk) + (int64_t)(h * DH + d) * F + f];
+    }
+    o[i] = at::f2bf(v);
+  }
 }
 
 using ShapeHSI = Shape<200, 1, 11, 1, 40, 10, 64>;
 using ShapeTiny1 = Shape<8, 1, 5, 1, 40, 2, 64>;
 
-template <class Sh>
-static hipError_t launch_attn(const AttnArgs& a, hipStream_t st) {
+#ifdef DMF_STAMPS
+hipError_t set_attn_stamps(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_astamps), &p, sizeof(p)); }
+#endif
+
+size_t attn_prep_bytes() { return (size_t)3 * AttnTrainLds<ShapeTiny1, 96, 3>::WPREP * 2; }
+
+hipError_t attn_prep_launch(const float* theta, int64_t oWq, int64_t oWk, int64_t oWv, int64_t oWo, void* out, hipStream_t st) {
+  hipLaunchKernelGGL((attn_prep_kernel<96, 3>), dim3(8, 3), dim3(256), 0, st, theta, oWq, oWk, oWv, oWo, static_cast<bfs*>(out));
+  return hipGetLastError();
+}
+
+template <class Sh, bool TRAIN>
+static hipError_t launch_attn_train(const AttnTrainArgs& a, int grid, hipStream_t st) {
   static bool done = false;
-  const size_t bytes = attn_lds_bytes<Sh, 96, 3>();
+  constexpr size_t bytes = AttnTrainLds<Sh, 96, 3>::BYTES;
+  static_assert(bytes <= 160 * 1024, "attention kernel LDS");
   if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_head_kernel<Sh, 96, 3>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_train_kernel<Sh, 96, 3, TRAIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     done = true;
   }
-  const int grid = a.B < 1024 ? a.B : 1024;
-  hipLaunchKernelGGL((attn_head_kernel<Sh, 96, 3>), dim3(grid), dim3(512), bytes, st, a);
+  hipLaunchKernelGGL((attn_train_kernel<Sh, 96, 3, TRAIN>), dim3(grid), dim3(512), bytes, st, a);
   return hipGetLastError();
+}
+
+hipError_t attn_train_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st) {
+  if (s.C == 200) return launch_attn_train<ShapeHSI, true>(a, grid, st);
+  if (s.C == 8) return launch_attn_train<ShapeTiny1, true>(a, grid, st);
+  return hipErrorInvalidValue;
+}
+
+hipError_t attn_forward_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st) {
+  if (s.C == 200) return launch_attn_train<ShapeHSI, false>(a, grid, st);
+  if (s.C == 8) return launch_attn_train<ShapeTiny1, false>(a, grid, st);
+  return hipErrorInvalidValue;
 }
 
 int attn_shape_supported(const dmf_shape& s) {
   if (s.E != 96 || s.heads != 3 || s.F != 40 || s.H != 64) return 0;
   return (s.C == 200 && s.C2 == 1 && s.P == 11 && s.S == 1 && s.G == 10) || (s.C == 8 && s.C2 == 1 && s.P == 5 && s.S == 1 && s.G == 2);
-}
-
-hipError_t attn_dispatch(const dmf_shape& s, const AttnArgs& a, hipStream_t st) {
-  if (s.C == 200) return launch_attn<ShapeHSI>(a, st);
-  if (s.C == 8) return launch_attn<ShapeTiny1>(a, st);
-  return hipErrorInvalidValue;
 }
 
 }  // namespace dmf

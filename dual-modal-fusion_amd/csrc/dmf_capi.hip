@@ -38,18 +38,7 @@ struct KArgs {   // must match dmf_patch_kernel.hip
 };
 enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4 };
 
-struct AttnArgs {   // must match dmf_attention.hip
-  const unsigned short* tokA;
-  const unsigned short* tokB;
-  const float* zin;
-  const float* theta;
-  const float* pool;
-  float* logits;
-  int32_t* pred;
-  int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
-  int32_t B, K;
-};
-struct AttnTrainArgs {   // must match dmf_attention_train.hip
+struct AttnTrainArgs {   // must match dmf_attention.hip
   const unsigned short* tokA; const unsigned short* tokB;
   const float* zin;
   const float* theta; const float* pool;
@@ -60,12 +49,16 @@ struct AttnTrainArgs {   // must match dmf_attention_train.hip
   float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;
   float* dYa; float* dYb;
   float* aslab;
+  int32_t* pred;
+  const unsigned short* wprep;
   int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
   int32_t B, K;
 };
+size_t attn_prep_bytes();
+hipError_t attn_prep_launch(const float* theta, int64_t oWq, int64_t oWk, int64_t oWv, int64_t oWo, void* out, hipStream_t st);
 hipError_t attn_train_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st);
+hipError_t attn_forward_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st);
 int attn_shape_supported(const dmf_shape& s);
-hipError_t attn_dispatch(const dmf_shape& s, const AttnArgs& a, hipStream_t st);
 
 struct QuaArgs {   // must match dmf_qua.hip
   const float* logits; int bs, K;
@@ -78,6 +71,7 @@ hipError_t launch_pair_argmax(const float* logits, int bs, int K, int32_t* pred,
 hipError_t launch_band_mean(const float* x, int layout, int64_t n_img, int64_t n_pix, int C, float* out, hipStream_t st);
 
 #ifdef DMF_STAMPS
+hipError_t set_attn_stamps(unsigned long long* p);
 hipError_t set_stamps(unsigned long long* p);
 #endif
 int patch_shape_supported(const dmf_shape& s);
@@ -354,7 +348,8 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
 
 int64_t dmf_attn_workspace_bytes(const dmf_shape* s, int32_t B) {
   if (s == nullptr || B < 0) return -1;
-  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4);      // two bf16 token maps + pooled z per patch
+  // two bf16 token maps + pooled z per patch + the bf16 weight copies of every head
+  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4) + (int64_t)attn_prep_bytes();
 }
 
 int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
@@ -366,25 +361,30 @@ int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* t
   if (!attn_shape_supported(*s)) return fail("%s", "no compiled attention instance for this shape (E = 96, heads = 3, F = 40)");
   if (in->B <= 0) return in->B == 0 ? 0 : fail("%s", "negative batch");
   const Layout L = layout_of(*s);
+  const size_t B = (size_t)in->B;
   unsigned short* tokA = static_cast<unsigned short*>(workspace);
-  unsigned short* tokB = tokA + (size_t)in->B * 128 * 64;
-  float* z = reinterpret_cast<float*>(tokB + (size_t)in->B * 128 * 64);
+  unsigned short* tokB = tokA + B * 128 * 64;
+  float* z = reinterpret_cast<float*>(tokB + B * 128 * 64);
+  unsigned short* wprep = reinterpret_cast<unsigned short*>(z + B * 2 * s->F);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (check(attn_prep_launch(theta, L.off[12], L.off[13], L.off[14], L.off[15], wprep, st), "attention weight prep launch")) return 1;
   KArgs a{};
   a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
   a.tokA = tokA; a.tokB = tokB; a.zout = z;
-  if (check(patch_dispatch(*s, MODE_TOKENS, a, static_cast<hipStream_t>(stream)), "token kernel launch")) return 1;
-  AttnArgs t{};
-  t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w; t.logits = logits; t.pred = pred;
+  if (check(patch_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
+  AttnTrainArgs t{};
+  t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w; t.logits = logits; t.pred = pred; t.wprep = wprep;
   t.oWq = L.off[12]; t.oWk = L.off[13]; t.oWv = L.off[14]; t.oWo = L.off[15];
   t.oFc1w = L.off[8]; t.oFc1b = L.off[9]; t.oFc2w = L.off[10]; t.oFc2b = L.off[11];
   t.B = in->B; t.K = s->K;
-  return check(attn_dispatch(*s, t, static_cast<hipStream_t>(stream)), "attention kernel launch");
+  const int grid = in->B < 2 * MAX_BLOCKS ? in->B : 2 * MAX_BLOCKS;
+  return check(attn_forward_dispatch(*s, t, grid, st), "attention kernel launch");
 }
 
 int64_t dmf_attn_train_workspace_bytes(const dmf_shape* s, int32_t B) {
   if (s == nullptr || B < 0) return -1;
-  // two bf16 token maps + pooled z + the two dense gradient maps [B][F][P*P]
-  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4 + 2 * (int64_t)s->F * s->P * s->P * 4);
+  // two bf16 token maps + pooled z + the two dense gradient maps [B][F][P*P] + the bf16 weight copies of every head
+  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4 + 2 * (int64_t)s->F * s->P * s->P * 4) + (int64_t)attn_prep_bytes();
 }
 
 int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
@@ -407,7 +407,9 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
   float* z = reinterpret_cast<float*>(tokB + B * 128 * 64);
   float* dYa = z + B * 2 * s->F;
   float* dYb = dYa + B * s->F * s->P * s->P;
+  unsigned short* wprep = reinterpret_cast<unsigned short*>(dYb + B * s->F * s->P * s->P);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (check(attn_prep_launch(theta, L.off[12], L.off[13], L.off[14], L.off[15], wprep, st), "attention weight prep launch")) return 1;
   KArgs a{};
   a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
   a.tokA = tokA; a.tokB = tokB; a.zout = z;
@@ -417,7 +419,7 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
   t.labels = labels; t.cursor = in->cursor; t.dlogits = dlogits; t.loss_scale = loss_scale;
   t.logits = logits; t.loss = loss;
   t.ws_z = ws + w.z; t.ws_h = ws + w.h; t.ws_dh = ws + w.dh; t.ws_dl = ws + w.dl;
-  t.dYa = dYa; t.dYb = dYb; t.aslab = ws + w.aslab;
+  t.dYa = dYa; t.dYb = dYb; t.aslab = ws + w.aslab; t.wprep = wprep;
   t.oWq = L.off[12]; t.oWk = L.off[13]; t.oWv = L.off[14]; t.oWo = L.off[15];
   t.oFc1w = L.off[8]; t.oFc1b = L.off[9]; t.oFc2w = L.off[10]; t.oFc2b = L.off[11];
   t.B = in->B; t.K = s->K;
@@ -653,6 +655,7 @@ int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, doubl
 }
 
 #ifdef DMF_STAMPS
+int32_t dmf_debug_set_attn_stamps(void* p) { return check(dmf::set_attn_stamps(static_cast<unsigned long long*>(p)), "set_attn_stamps"); }
 int32_t dmf_debug_set_stamps(void* p) { return check(dmf::set_stamps(static_cast<unsigned long long*>(p)), "set_stamps"); }
 #endif
 

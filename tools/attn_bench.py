@@ -1,7 +1,7 @@
-"""Forward throughput of the attention network (BASELINE configs[2]: 200-band HSI + 1-band LiDAR, cross-modal
+"""Forward and training-step throughput of the attention network (BASELINE configs[2]: 200-band HSI + 1-band LiDAR, cross-modal
 attention on, bf16 MFMA, batch 1024) — used under rocprofv3 for the MFMA counters in profiles/.
 
-    python tools/attn_bench.py [B] [iters]
+    python tools/attn_bench.py [B] [iters] [train]
 """
 import os
 import sys
@@ -48,6 +48,30 @@ def main():
     flops = 2.0 * (3 * 128 * 64 * 96 + 2 * 3 * 128 * 128 * 32 + 128 * 96 * 48)
     print('attention forward: B=%d  %.1f us / batch  %.2f M patches/s  %.1f TFLOP/s on the matrix cores (padded shapes)'
           % (B, dt * 1e6, B / dt / 1e6, B * flops / dt / 1e12))
+
+
+    if len(sys.argv) > 3 and sys.argv[3] == 'train':
+        from dmf.engine import TrainEngine
+        lab = torch.from_numpy(rng.integers(0, 17, B * 8).astype(np.int32)).cuda()
+        xy8 = torch.from_numpy(np.stack([rng.integers(0, 145, B * 8), rng.integers(0, 145, B * 8)], 1).astype(np.int32))
+        eng = TrainEngine(net, scene, B, lr=1e-3)
+        eng.load_plan(xy8, lab)
+        eng.run_plan(8, 0)
+        torch.cuda.synchronize()
+        n = 0
+        t0 = time.perf_counter()
+        while n < iters:
+            eng.dev_cursor.zero_()
+            eng.run_plan(8, 0)
+            n += 8
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        # backward matrix-core work per patch on top of a forward recompute: dQs, dK (3 heads x 2 x 128x128x32, hi+lo),
+        # dTa/dTb (2 x 128x32x48 per head, hi+lo), dWq/dWk (2 x 32x48x128 per head, hi+lo)
+        bflops = 2.0 * (2 * (2 * 3 * 128 * 128 * 32) + 2 * (2 * 3 * 128 * 32 * 48) + 2 * (2 * 3 * 32 * 48 * 128)) \
+            + 2.0 * 3 * 128 * 128 * 32     # S for own keys
+        print('attention train step (tokens + attention fwd/bwd + conv backward + reduce/ADAM): B=%d  %.1f us / step  '
+              '%.3f M patches/s  %.1f TFLOP/s on the matrix cores' % (B, dt * 1e6, B / dt / 1e6, B * (2 * flops + bflops) / dt / 1e12))
 
 
 if __name__ == '__main__':
