@@ -35,7 +35,7 @@ def make_cfg(args):
     return {'patch_size': args.patch, 'Categories_Number': K, 'data_city': 'syn',
             'DATA_DICT': {'syn': {'size': [args.size, args.size, args.bands], 'color': class_colors(K)}},
             'scale': 1, 'aux_bands': args.aux_bands,
-            'gmf': {'width': 32 if args.bands == 224 else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'gmf': {'width': args.width, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def build_problem(args, cfg):
@@ -76,6 +76,7 @@ def main():
     ap.add_argument('--size', type=int, default=145)
     ap.add_argument('--bands', type=int, default=200)
     ap.add_argument('--aux-bands', type=int, default=1)
+    ap.add_argument('--width', type=int, default=40, help='gmf.width: feature channels per branch (40 or 32)')
     ap.add_argument('--patch', type=int, default=11)
     ap.add_argument('--classes', type=int, default=16)
     ap.add_argument('--train-rate', type=float, default=0.10)
@@ -83,6 +84,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='CPU baseline budget (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
+    if args.bands == 224 and args.width == 40:
+        args.width = 32                     # the compiled 224-band instance
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

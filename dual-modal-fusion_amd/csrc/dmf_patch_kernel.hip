@@ -141,7 +141,11 @@ typedef const float __attribute__((address_space(4))) cfloat;
 template <class Sh>
 struct Lds {
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-  static constexpr int QG = Sh::Cg / 4;                            // 16-byte band chunks per spectral group
+  // 16-byte band chunks a wavefront reads per spectral group (misaligned groups: lead + Cg <= Cg + 3 floats)
+  static constexpr int QG = Sh::MISAL ? (Sh::Cg + 3 + 3) / 4 : Sh::Cg / 4;
+  // misaligned groups: the part of a group's band columns that no neighbour's aligned chunks can touch (smallest
+  // over the four leads); the spec_a gradient partials are packed into those private columns, row after row
+  static constexpr int PW = Sh::MISAL ? ((Sh::Cg - 3) / 4) * 4 : Sh::Cg;
   static constexpr int NSLW = (64 / QG) < 16 ? (64 / QG) : 16;     // pixel slices of a wave's spec_a gradient
   // partial sums of that gradient: a wave whose group is its own (M == 4) recycles its private band slice of the X
   // tile; groups shared by several waves (M > 4) get a dedicated region
@@ -162,6 +166,7 @@ struct Lds {
   static constexpr int TOKSCR = (Sh::P2 <= 128) ? 2 * 128 * 72 / 2 : 0;      // MODE_TOKENS staging (floats)
   static constexpr int SCR = cmax(Sh::P2 * Cs, TOKSCR);                      // X tile (later: token staging)
   static_assert(!OWN_SLICE || NSLW * 4 <= Sh::P2, "own-slice scratch needs NSLW*4 pixel rows");
+  static_assert(!Sh::MISAL || (OWN_SLICE && (NSLW * 4 * 4 * QG + PW - 1) / PW <= Sh::P2), "packed scratch fits the private columns");
   // offsets in floats
   static constexpr int oX = 0;
   static constexpr int oY1a = oX + SCR;                            // [F][P][RS]  spec_a output, later dY1a
@@ -435,6 +440,27 @@ __device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const u
     *reinterpret_cast<float4*>(row + 4 * k) = make_float4(dy[4 * k], dy[4 * k + 1], dy[4 * k + 2], dy[4 * k + 3]);
 }
 
+// spec_a of one pixel for 4 channels of one group: aligned 16-byte chunks of the pixel's band row, slot 4*q4 + i holds
+// band j = 4*q4 + i - LEAD of the group (slots outside [0, Cg) belong to neighbouring groups and are skipped); the
+// bands are accumulated in ascending order whatever the lead
+template <class Sh, int LEAD>
+__device__ __forceinline__ void spec_fwd_chunks(const float* xrow, cfloat* wg, float acc[4]) {
+#pragma unroll
+  for (int q4 = 0; q4 < Lds<Sh>::QG; ++q4) {
+    if (4 * q4 + 3 - LEAD < 0 || 4 * q4 - LEAD >= Sh::Cg) continue;
+    const float4 xv = *reinterpret_cast<const float4*>(xrow + 4 * q4);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * q4 + i - LEAD;
+      if (j >= 0 && j < Sh::Cg) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = fmaf(wg[m * Sh::Cg + j], xs[i], acc[m]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- the kernel
 template <class Sh, int MODE>
 __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
@@ -597,17 +623,13 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       float acc[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m] = thc[Sh::oA1b + g * Sh::M + mo + m];
-      const float* xrow = sX + pixc * L::Cs + g * Sh::Cg;
-#pragma unroll
-      for (int j4 = 0; j4 < Sh::Cg / 4; ++j4) {
-        const float4 xv = *reinterpret_cast<const float4*>(xrow + 4 * j4);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 0], xv.x, acc[m]);
-          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 1], xv.y, acc[m]);
-          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 2], xv.z, acc[m]);
-          acc[m] = fmaf(wg[m * Sh::Cg + 4 * j4 + 3], xv.w, acc[m]);
-        }
+      const int lead = Sh::MISAL ? ((g * Sh::Cg) & 3) : 0;          // wave-uniform
+      const float* xrow = sX + pixc * L::Cs + g * Sh::Cg - lead;     // 16-byte aligned
+      switch (lead) {
+        case 0: spec_fwd_chunks<Sh, 0>(xrow, wg, acc); break;
+        case 1: if constexpr (Sh::MISAL) spec_fwd_chunks<Sh, 1>(xrow, wg, acc); break;
+        case 2: if constexpr (Sh::MISAL) spec_fwd_chunks<Sh, 2>(xrow, wg, acc); break;
+        default: if constexpr (Sh::MISAL) spec_fwd_chunks<Sh, 3>(xrow, wg, acc); break;
       }
       if (valid) {
 #pragma unroll
@@ -861,7 +883,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       const int cc = ln % QG, sl = ln / QG;
       const int blk = wave;
       const int g = (4 * blk) / Sh::M;
-      const int band0 = g * Sh::Cg + 4 * cc;
+      const int lead = Sh::MISAL ? ((g * Sh::Cg) & 3) : 0;          // slot 4*cc + i holds band 4*cc + i - lead of the group
+      const int band0 = g * Sh::Cg - lead + 4 * cc;
       float acc[4][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.f;
@@ -891,6 +914,33 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
       // tile (only this wave ever touches them, and it has finished reading them: same wave, program order).
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if constexpr (Sh::MISAL) {
+        // packed scratch: partial (row = sl*4 + m, slot) -> element e = row * 4QG + slot of a [rows][PW] array that
+        // lives in the group's private band columns (first aligned column at or after the group's first band)
+        float* pbase = sX + g * Sh::Cg + ((4 - lead) & 3);
+        constexpr int SW = 4 * QG;
+        if (sl < NSLW) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int e = (sl * 4 + m) * SW + 4 * cc;               // 4 consecutive slots never straddle a PW row: PW % 4 == 0
+            *reinterpret_cast<float4*>(pbase + (e / L::PW) * L::Cs + (e % L::PW)) = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e0 = ln; e0 < 4 * Sh::Cg; e0 += 64) {
+          const int m = e0 / Sh::Cg, j = e0 - m * Sh::Cg;
+          float sacc = 0.f;
+#pragma unroll
+          for (int q = 0; q < NSLW; ++q) {
+            const int e = (q * 4 + m) * SW + j + lead;
+            sacc += pbase[(e / L::PW) * L::Cs + (e % L::PW)];
+          }
+          const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
+          slab[o] = first ? sacc : slab[o] + sacc;
+        }
+      } else {
       float* scr = L::OWN_SLICE ? (sX + g * Sh::Cg) : (sGscr + blk * (NSLW * 4 * Sh::Cg));
       constexpr int SROW = L::OWN_SLICE ? L::Cs : Sh::Cg;
       if (sl < NSLW) {
@@ -909,6 +959,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
         slab[o] = first ? sacc : slab[o] + sacc;
       }
+      }   // aligned groups
     }
     LDS_BARRIER();
     STAMP(10);
@@ -965,6 +1016,7 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
 
 // Compiled instances.  (C, C2, P, S, F, G, H)
 using ShapeHSI = Shape<200, 1, 11, 1, 40, 10, 64>;    // BASELINE configs 1-3: 200-band HSI + 1-band SAR/LiDAR, 11x11
+using ShapeHSI32 = Shape<200, 1, 11, 1, 32, 8, 64>;    // the same data at gmf.width 32: 8 groups of 25 bands, 8 wavefronts (2 per SIMD)
 using ShapeHSI224 = Shape<224, 3, 11, 1, 32, 8, 64>;  // BASELINE config 4: 224-band HSI + 3-band SAR (gmf.width 32)
 using ShapePanMs = Shape<4, 1, 16, 4, 40, 1, 64>;     // the reference's own data: 4-band MS + PAN at 4x, patch 16
 using ShapeTiny = Shape<8, 1, 5, 4, 40, 2, 64>;       // small test scene (tests/golden/g9_trajectory.npz)
@@ -979,12 +1031,13 @@ static bool matches(const dmf_shape& s) {
 
 int patch_shape_supported(const dmf_shape& s) {
   if (s.K < 1 || s.K > KMAX) return 0;
-  return matches<ShapeHSI>(s) || matches<ShapeHSI224>(s) || matches<ShapePanMs>(s) || matches<ShapeTiny>(s) ||
+  return matches<ShapeHSI>(s) || matches<ShapeHSI32>(s) || matches<ShapeHSI224>(s) || matches<ShapePanMs>(s) || matches<ShapeTiny>(s) ||
          matches<ShapeTiny1>(s) || matches<ShapeQua>(s) || matches<ShapeQuaTiny>(s);
 }
 
 hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
   if (matches<ShapeHSI>(s)) return launch_patch<ShapeHSI>(mode, a, st);
+  if (matches<ShapeHSI32>(s)) return launch_patch<ShapeHSI32>(mode, a, st);
   if (matches<ShapeHSI224>(s)) return launch_patch<ShapeHSI224>(mode, a, st);
   if (matches<ShapePanMs>(s)) return launch_patch<ShapePanMs>(mode, a, st);
   if (matches<ShapeTiny>(s)) return launch_patch<ShapeTiny>(mode, a, st);

@@ -14,6 +14,10 @@ struct Shape {
   static constexpr int P2 = P * P;          // pixels (tokens) per patch
   static constexpr int Cg = C / G;          // bands per spectral group
   static constexpr int M = F / G;           // outputs per spectral group
+  // MISAL: a group's first band is not 16-byte aligned in the pixel row (Cg % 4 != 0).  The kernel then reads the
+  // group through aligned 16-byte chunks that start up to 3 bands early (lead = (g*Cg) & 3) and skips the slots that
+  // belong to the neighbours; supported when a wavefront owns a whole group (M == 4).
+  static constexpr bool MISAL = (Cg % 4) != 0;
   static constexpr int SP = S * P;          // aux patch side
   static constexpr int PB = SP * SP;        // aux pixels per patch
   static constexpr int TB = C2 * S * S;     // taps of the lift conv
@@ -41,7 +45,7 @@ struct Shape {
   static constexpr int SLAB = (NCONV + 31) & ~31;   // slab row pitch (floats)
 
   static_assert(C % G == 0 && F % G == 0, "groups must divide C and F");
-  static_assert(Cg % 4 == 0, "bands per group must be a multiple of 4 (16-byte chunks)");
+  static_assert(Cg % 4 == 0 || M == 4, "bands per group: a multiple of 4 (16-byte chunks), or one wavefront per group");
   static_assert(F % 4 == 0 && M % 4 == 0, "a wavefront owns a block of 4 channels inside one spectral group");
   static_assert(P <= 16, "one 16-lane group holds the rows of a patch");
   static_assert(F * 16 <= NT && NT <= 1024, "one 16-lane row group per channel");

@@ -17,6 +17,7 @@ SHAPES = {
     'tiny': (8, 1, 5, 4, 5),
     'tiny1': (8, 1, 5, 1, 5),
     'hsi': (200, 1, 11, 1, 17),
+    'hsi32': (200, 1, 11, 1, 17),    # gmf.width 32: 8 groups of 25 bands (misaligned groups), 8 wavefronts
     'hsi224': (224, 3, 11, 1, 17),
     'panms': (4, 1, 16, 4, 12),
     'qua': (4, 1, 16, 1, 12),        # stage 2 of the two-stage path: one 4-band stream + its band mean
@@ -28,7 +29,7 @@ def make_cfg(name):
     C, C2, P, S, K = SHAPES[name]
     return {'patch_size': P, 'Categories_Number': K, 'data_city': 's', 'DATA_DICT': {'s': {'size': [64, 64, C]}},
             'scale': S, 'aux_bands': C2,
-            'gmf': {'width': 32 if name == 'hsi224' else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'gmf': {'width': 32 if name in ('hsi224', 'hsi32') else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def nets(name, seed=0):
@@ -74,10 +75,10 @@ def assert_close(got, want, atol, rtol, what):
         np.unravel_index(int(err.argmax()), tuple(err.shape)) if err.dim() else ())
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
 @pytest.mark.parametrize('B', [1, 37, 300])
 def test_forward_patches(name, B):
-    if name in ('hsi224', 'panms') and B == 300:
+    if name in ('hsi224', 'hsi32', 'panms') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -96,7 +97,7 @@ def _scene(name, H=23, W=19, seed=5):
     return A, Bm
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
 def test_forward_gather_and_pred(name):
     from dmf import lib
     C, C2, P, S, K = SHAPES[name]
@@ -125,11 +126,11 @@ def test_forward_gather_and_pred(name):
     assert torch.equal(pred.cpu().long()[safe], want.argmax(1)[safe])
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny'])
+@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
 @pytest.mark.parametrize('B', [3, 64, 300])
 def test_train_fwd_bwd_grads(name, B):
     from dmf import lib
-    if name in ('hsi224', 'panms') and B == 300:
+    if name in ('hsi224', 'hsi32', 'panms') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -153,7 +154,7 @@ def test_train_fwd_bwd_grads(name, B):
         assert_close(g, want_g[k], 1e-5, 1e-4, 'grad %s [%s,B=%d]' % (k, name, B))
 
 
-@pytest.mark.parametrize('name', ['tiny', 'hsi'])
+@pytest.mark.parametrize('name', ['tiny', 'hsi', 'hsi32'])
 def test_train_gather_equals_patches(name):
     """Both input modes feed the same arithmetic: bit-identical logits, loss and gradient."""
     from dmf import lib

@@ -1,6 +1,6 @@
 """Diagnostic: per-phase cycle shares of the fused patch kernel (stamps build, never the shipped library).
 
-    DMF_LIB=dual-modal-fusion_amd/dmf/libdmf_hip_stamps.so python tools/phase_profile.py [B]
+    DMF_LIB=dual-modal-fusion_amd/dmf/libdmf_hip_stamps.so python tools/phase_profile.py [B] [width]
 """
 import ctypes as C
 import os
@@ -24,8 +24,9 @@ NAMES = ['issue gather + aux branch fwd', 'wait window (barrier)', 'spec_a + spa
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    width = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     cfg = {'patch_size': 11, 'Categories_Number': 17, 'data_city': 's', 'DATA_DICT': {'s': {'size': [145, 145, 200]}},
-           'scale': 1, 'aux_bands': 1, 'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+           'scale': 1, 'aux_bands': 1, 'gmf': {'width': width, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
     primary, aux, label = synth.make_scene(145, 145, 200, 1, 1, seed=0)
     MS = data_padding(primary, cfg, 'ms').astype(np.float32)
     PAN = data_padding_aux(aux, cfg).astype(np.float32)
