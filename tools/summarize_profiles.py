@@ -18,6 +18,11 @@ import os
 import statistics
 import sys
 
+
+def newest(files):
+    return sorted(files, key=os.path.getmtime)[-1:]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -25,14 +30,14 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
     out = os.path.join(ROOT, 'profiles')
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof_' + tag, '**', '*_kernel_stats.csv'), recursive=True)
+    stats = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof_' + tag, '**', '*_kernel_stats.csv'), recursive=True))
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(out, tag + '_kernel_stats.csv'), 'w', newline='') as f:
             csv.writer(f).writerows(rows[:12])
     pmc = {}
     for name, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
-        files = glob.glob(os.path.join(ROOT, 'gpurun_out', name, '**', '*_counter_collection.csv'), recursive=True)
+        files = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', name, '**', '*_counter_collection.csv'), recursive=True))
         if not files:
             continue
         d = collections.defaultdict(list)
@@ -52,6 +57,41 @@ def main():
     json.dump(summary, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
     json.dump(summary, open(os.path.join(out, tag + '_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(summary, indent=1)[:1500])
+    # ---- attention network: kernel stats of a train step + matrix-core counters of the attention kernels
+    stats = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof_' + tag + 'attn', '**', '*_kernel_stats.csv'), recursive=True))
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(os.path.join(out, tag + '_attn_kernel_stats.csv'), 'w', newline='') as f:
+            csv.writer(f).writerows(rows[:10])
+    files = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', 'pmc_attn', '**', '*_counter_collection.csv'), recursive=True))
+    if files:
+        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        dur = collections.defaultdict(list)
+        seen = set()
+        for r in csv.DictReader(open(files[0])):
+            if 'attn_train_kernel' not in r['Kernel_Name']:
+                continue
+            k = 'attn_train_kernel<..., TRAIN=%s>' % ('true' if 'true>' in r['Kernel_Name'] or ', 1>' in r['Kernel_Name'] else 'false')
+            d[k][r['Counter_Name']].append(float(r['Counter_Value']))
+            key = (k, r.get('Dispatch_Id'))
+            if key not in seen and r.get('End_Timestamp') and r.get('Start_Timestamp'):
+                seen.add(key)
+                dur[k].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
+        res = {'command': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace '
+                          '--output-format csv -- python3 tools/attn_bench.py 1024 40 train', 'batch': 1024, 'kernels': {}}
+        for k, c in d.items():
+            med = {n: statistics.median(v) for n, v in c.items()}
+            e = {'median_counters': med, 'launches': len(next(iter(c.values())))}
+            if dur[k]:
+                e['median_duration_ns_under_pmc'] = statistics.median(dur[k])
+            if 'SQ_INSTS_MFMA' in med:
+                e['mfma_instructions_per_launch'] = med['SQ_INSTS_MFMA']
+            if 'SQ_VALU_MFMA_BUSY_CYCLES' in med and 'GRBM_GUI_ACTIVE' in med and med['GRBM_GUI_ACTIVE'] > 0:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs can each be MFMA-busy every cycle
+                e['mfma_busy_fraction_of_all_simds'] = med['SQ_VALU_MFMA_BUSY_CYCLES'] / (med['GRBM_GUI_ACTIVE'] / 8.0 * 256 * 4)
+            res['kernels'][k] = e
+        json.dump(res, open(os.path.join(out, tag + '_attn_mfma.json'), 'w'), indent=1)
+        print(json.dumps(res, indent=1)[:1500])
 
 
 if __name__ == '__main__':
