@@ -146,6 +146,22 @@ def main():
 
     # ---- warm-up (W steps; also builds the graph), then EXACTLY K timed steps
     eng.run_plan(W_steps, 0)
+    if comm is not None:
+        # the exchange has now run W real steps: if any rank saw a wait time out, every rank drops to the RCCL
+        # all-reduce and repeats the warm-up from the initial weights (decided together, before anything is timed)
+        import torch.distributed as dist
+        bad = torch.tensor([comm.status()], dtype=torch.int32, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) != 0:
+            if rank == 0:
+                print('[bench] one-shot exchange timed out during warm-up; falling back to the RCCL all-reduce',
+                      file=sys.stderr, flush=True)
+            comm = None
+            net.load_state_dict(init_state)
+            eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=None)
+            eng.load_plan(xy_tab[mine], lab_tab[mine])
+            spg = 0
+            eng.run_plan(W_steps, 0)
     if spg:
         eng._capture(spg)                       # capture restores state: no steps are consumed
     sync()
