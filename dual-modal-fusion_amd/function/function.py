@@ -61,13 +61,27 @@ def read_tif(cfg, mode):
         filename = cfg['data_address'] + 'pan.tif'
     else:
         raise ValueError("mode")
-    if os.path.exists(filename + '.npy'):
+    if os.path.exists(filename + '.npy'):                      # pre-converted scene (tools/make_synthetic_scene.py)
         return np.load(filename + '.npy')
+    from function.tiffio import read_image                     # function.py:40-42 uses libtiff.TIFF.read_image
+    return read_image(filename)
+
+
+def label_mat2np(cfg):
+    """function/function.py:11-17: `label.mat` -> `label.npy` (uint8, transposed).  The reference opens the file with
+    h5py (MATLAB v7.3); h5py is not importable here, so MATLAB v5 / v7 files are read with scipy.io.loadmat — those are
+    stored in MATLAB's column-major order already transposed back by scipy, hence no transpose on that route — and a
+    v7.3 file fails with a clear message."""
+    path = cfg['data_address']
     try:
-        from libtiff import TIFF
-    except ImportError as e:
-        raise FileNotFoundError('%s.npy not found and no TIFF reader (libtiff) is importable' % filename) from e
-    return TIFF.open(filename, mode='r').read_image()
+        import scipy.io
+        label = np.array(scipy.io.loadmat(path + 'label.mat')['label'], dtype='uint8')
+    except NotImplementedError as e:                           # scipy: "Please use HDF reader for matlab v7.3 files"
+        raise NotImplementedError(path + 'label.mat is a MATLAB v7.3 (HDF5) file and h5py is not installed; '
+                                  'convert it to label.npy (np.transpose of the stored array) elsewhere') from e
+    print(label.shape)
+    np.save(path + 'label.npy', label)
+    return label
 
 
 def data_show(matrix):

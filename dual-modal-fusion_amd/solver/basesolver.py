@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Subset
 
-from function.function import data_padding, data_padding_aux, data_show, read_tif, split_data_old
+from function.function import data_padding, data_padding_aux, data_show, label_mat2np, read_tif, split_data_old
 from indicators.kappa import aa_oa, expo_result
 from train.dataset import dataset_dual
 
@@ -38,7 +38,7 @@ class BaseSolver:
 
         label_path = cfg['data_address'] + 'label.npy'
         if not os.path.exists(label_path):
-            raise FileNotFoundError(label_path + ' (label.mat conversion needs h5py, which this image lacks)')
+            label_mat2np(cfg)                                   # basesolver.py:34-35
         label_np = np.load(label_path)
         data_show(label_np)
         self.label_np = label_np

@@ -236,3 +236,64 @@ def test_data_parallel_gradient_equals_global_batch_gloo():
     torch.nn.functional.cross_entropy(net(a, b), t).backward()
     want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
     assert np.allclose(got, want, atol=1e-6)
+
+
+def test_tiff_reader_matches_pillow_and_roundtrips():
+    """function.tiffio (libtiff is absent): strips / tiles, LZW / Deflate / PackBits / none, predictor 2, both byte
+    orders are checked against files Pillow's libtiff writes; multi-band uint16 / float32 scenes (what `ms4.tif` is,
+    and what Pillow cannot express) round-trip through the module's own writer, plain and Deflate."""
+    from PIL import Image
+    from function import tiffio
+    rng = np.random.default_rng(0)
+    tmp = tempfile.mkdtemp(prefix='dmf_tif_')
+    try:
+        g8 = rng.integers(0, 255, (37, 53), dtype=np.uint8)
+        g8[5:20, 5:40] = 7                                       # runs, so that the compressors do something
+        rgb = rng.integers(0, 255, (37, 53, 3), dtype=np.uint8)
+        rgb[10:30] = rgb[10:11]
+        g16 = rng.integers(0, 60000, (37, 53), dtype=np.uint16)
+        cases = [(g8, 'L'), (rgb, 'RGB'), (g16, 'I;16')]
+        for arr, mode in cases:
+            for comp in ('raw', 'tiff_lzw', 'tiff_adobe_deflate', 'packbits'):
+                p = os.path.join(tmp, 'a_%s_%s.tif' % (mode.replace(';', ''), comp))
+                Image.fromarray(arr).save(p, compression=comp)
+                got = tiffio.read_image(p)
+                assert got.shape == arr.shape and got.dtype == arr.dtype and np.array_equal(got, arr), (mode, comp)
+        p = os.path.join(tmp, 'tiled.tif')
+        Image.fromarray(rgb).save(p, compression='tiff_lzw', tiffinfo={317: 2, 322: 16, 323: 16})
+        assert np.array_equal(tiffio.read_image(p), rgb)
+        ms = rng.integers(0, 4000, (41, 29, 4), dtype=np.uint16)  # a 4-band MS scene
+        hsi = rng.standard_normal((17, 19, 200)).astype(np.float32)
+        for arr in (ms, hsi, g16.astype(np.int32) - 30000):
+            for comp in (False, True):
+                p = os.path.join(tmp, 'own.tif')
+                tiffio.write_image(p, arr, rows_per_strip=7, compress=comp)
+                got = tiffio.read_image(p)
+                assert got.dtype == arr.dtype and np.array_equal(got, arr)
+        p = os.path.join(tmp, 'pil_reads_ours.tif')
+        tiffio.write_image(p, g16)
+        assert np.array_equal(np.array(Image.open(p)), g16)       # an independent reader accepts the writer's files
+        with pytest.raises(tiffio.TiffError):
+            open(p, 'wb').write(b'not a tiff file'); tiffio.read_image(p)
+    finally:
+        shutil.rmtree(tmp)
+
+
+def test_read_tif_and_label_mat(golden_dir):
+    """`read_tif` opens real .tif scenes and `label_mat2np` converts a MATLAB v5 label file (function.py:11-17,33-42)."""
+    import scipy.io
+    from function import tiffio
+    from function.function import label_mat2np, read_tif
+    tmp = tempfile.mkdtemp(prefix='dmf_ingest_') + '/'
+    try:
+        rng = np.random.default_rng(1)
+        ms = rng.integers(0, 4000, (12, 10, 4), dtype=np.uint16)
+        pan = rng.integers(0, 4000, (48, 40), dtype=np.uint16)
+        tiffio.write_image(tmp + 'ms4.tif', ms); tiffio.write_image(tmp + 'pan.tif', pan)
+        cfg = {'data_address': tmp}
+        assert np.array_equal(read_tif(cfg, 'ms'), ms) and np.array_equal(read_tif(cfg, 'pan'), pan)
+        lab = rng.integers(0, 5, (12, 10)).astype(np.uint8)
+        scipy.io.savemat(tmp + 'label.mat', {'label': lab})
+        assert np.array_equal(label_mat2np(cfg), lab) and np.array_equal(np.load(tmp + 'label.npy'), lab)
+    finally:
+        shutil.rmtree(tmp)
