@@ -184,16 +184,26 @@ def read_image(path):
     return img[:, :, 0] if img.shape[2] == 1 else img
 
 
-def write_image(path, array, rows_per_strip=64, compress=False):
-    """Uncompressed (or Deflate) little-endian strip TIFF, chunky samples — the writer the tests and
-    tools/make_synthetic_scene.py use to produce `ms4.tif` / `pan.tif` files any TIFF reader opens."""
+def write_image(path, array, rows_per_strip=64, compress=False, tile=None):
+    """Uncompressed (or Deflate) little-endian TIFF with chunky samples, in strips or (tile=(th, tw), multiples of 16)
+    tiles — the writer the tests use to produce `ms4.tif` / `pan.tif` files any TIFF reader opens."""
     a = np.ascontiguousarray(array)
     if a.ndim == 2:
         a = a[:, :, None]
     H, W, C = a.shape
     kind = {'u': 1, 'i': 2, 'f': 3}[a.dtype.kind]
     a = a.astype(a.dtype.newbyteorder('<'))
-    strips = [a[r:r + rows_per_strip].tobytes() for r in range(0, H, rows_per_strip)]
+    if tile is not None:
+        th, tw = tile
+        strips = []
+        for ty in range(0, H, th):
+            for tx in range(0, W, tw):
+                t = np.zeros((th, tw, C), dtype=a.dtype)
+                blk = a[ty:ty + th, tx:tx + tw]
+                t[:blk.shape[0], :blk.shape[1]] = blk
+                strips.append(t.tobytes())
+    else:
+        strips = [a[r:r + rows_per_strip].tobytes() for r in range(0, H, rows_per_strip)]
     if compress:
         strips = [zlib.compress(s) for s in strips]
     n = len(strips)
@@ -206,8 +216,13 @@ def write_image(path, array, rows_per_strip=64, compress=False):
         entries.append((tag, typ, len(values), data))
 
     add(256, 4, [W]); add(257, 4, [H]); add(258, 3, [a.dtype.itemsize * 8] * C); add(259, 3, [8 if compress else 1])
-    add(262, 3, [1]); add(277, 3, [C]); add(278, 4, [rows_per_strip]); add(284, 3, [1]); add(339, 3, [kind] * C)
-    add(273, 4, [0] * n); add(279, 4, [len(s) for s in strips])
+    add(262, 3, [1]); add(277, 3, [C]); add(284, 3, [1]); add(339, 3, [kind] * C)
+    OFF, CNT = (324, 325) if tile is not None else (273, 279)
+    if tile is not None:
+        add(322, 4, [tile[1]]); add(323, 4, [tile[0]])
+    else:
+        add(278, 4, [rows_per_strip])
+    add(OFF, 4, [0] * n); add(CNT, 4, [len(s) for s in strips])
     entries.sort(key=lambda e: e[0])
     ifd_off = 8
     ifd_len = 2 + 12 * len(entries) + 4
@@ -226,14 +241,14 @@ def write_image(path, array, rows_per_strip=64, compress=False):
         f.write(b'II' + struct.pack('<HI', 42, ifd_off))
         f.write(struct.pack('<H', len(entries)))
         for tag, typ, cnt, data in entries:
-            if tag == 273:
+            if tag == OFF:
                 data = struct.pack('<' + 'I' * n, *strip_off)
             f.write(struct.pack('<HHI', tag, typ, cnt))
             f.write(struct.pack('<I', blobs[tag]) if len(data) > 4 else data.ljust(4, b'\x00'))
         f.write(struct.pack('<I', 0))
         for tag, typ, cnt, data in entries:
             if len(data) > 4:
-                if tag == 273:
+                if tag == OFF:
                     data = struct.pack('<' + 'I' * n, *strip_off)
                 f.write(data + (b'\x00' if len(data) & 1 else b''))
         for s in strips:
