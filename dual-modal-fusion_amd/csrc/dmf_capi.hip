@@ -530,7 +530,7 @@ int32_t dmf_xgmi_sizes(int64_t capacity, int32_t world, int64_t* data_bytes, int
   if (capacity <= 0 || world < 1 || world > XGMI_MAX || data_bytes == nullptr || flag_bytes == nullptr)
     return fail("%s", "bad xgmi_sizes argument");
   const int64_t cap = (capacity + 255) / 256 * 256;
-  *data_bytes = 4 * cap * (int64_t)sizeof(float);
+  *data_bytes = 4 * cap * world * (int64_t)sizeof(float);      // inbox: [region 2][parity 2][src world][cap]
   *flag_bytes = (xgmi_status_index(world, xgmi_nblk(cap)) + 16) * (int64_t)sizeof(int32_t);
   return 0;
 }

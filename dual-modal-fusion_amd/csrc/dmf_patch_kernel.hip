@@ -491,31 +491,62 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   const int B = a.in.B;
   float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB;
 
-  for (int i = tid0; i < Sh::P * L::RS; i += Sh::NT) {   // pooling profile, rows padded to RS
-    const int r = i / L::RS, c = i - r * L::RS;
-    sPool[i] = c < Sh::P ? a.pool[r * Sh::P + c] : 0.f;
-  }
+  STAMP(11);
+  // Prologue.  The patch-invariant tables (pooling profile, depthwise taps, fc2 rows) are fetched into registers
+  // first, the first patch's window gather is issued second, and only then do the tables go to LDS: their global-load
+  // latency and the gather's overlap, and the final barrier waits on LDS traffic only (the gather stays in flight).
+  constexpr int NPRE_P = (Sh::P * L::RS + Sh::NT - 1) / Sh::NT, NPRE_D = (2 * Sh::F * 12 + Sh::NT - 1) / Sh::NT;
+  constexpr int NPRE_W = (L::W2ROWS * Sh::H + Sh::NT - 1) / Sh::NT;
+  constexpr bool AUX_WAVE = (Sh::PB * Sh::C2 <= 256);        // small aux tile: every wave loads its own copy
   float* sDww = smem + L::oDww;
-  for (int i = tid0; i < 2 * Sh::F * 12; i += Sh::NT) {   // depthwise taps + bias of both branches: [branch][F][12]
-    const int br = i / (Sh::F * 12), rem = i - br * (Sh::F * 12);
-    const int f = rem / 12, k = rem - f * 12;
-    float v = 0.f;
-    if (k < 9) v = th[(unsigned)((br ? Sh::oB2w : Sh::oA2w) + f * 9 + k)];
-    else if (k == 9) v = th[(unsigned)((br ? Sh::oB2b : Sh::oA2b) + f)];
-    sDww[i] = v;
-  }
   float* sB2 = smem + L::oW2;                 // fc2.bias [KMAX]
   float* sW2 = sB2 + KMAX;                    // fc2.weight rows 0..min(K, W2ROWS)-1, [row][H]
   const int kst = K < L::W2ROWS ? K : L::W2ROWS;
-  for (int i = tid0; i < kst * Sh::H; i += Sh::NT) sW2[i] = th[(unsigned)(Sh::oFc2w + i)];
-  for (int i = tid0; i < KMAX; i += Sh::NT) sB2[i] = i < K ? th[(unsigned)(Sh::oFc2w + K * Sh::H + i)] : 0.f;
+  float preP[NPRE_P], preD[NPRE_D], preW[NPRE_W], preB = 0.f;
+#pragma unroll
+  for (int q = 0; q < NPRE_P; ++q) {          // pooling profile, rows padded to RS
+    const int i = tid0 + q * Sh::NT, r = i / L::RS, c = i - r * L::RS;
+    preP[q] = (i < Sh::P * L::RS && c < Sh::P) ? a.pool[r * Sh::P + c] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NPRE_D; ++q) {          // depthwise taps + bias of both branches: [branch][F][12]
+    const int i = tid0 + q * Sh::NT;
+    const int br = i / (Sh::F * 12), rem = i - br * (Sh::F * 12);
+    const int f = rem / 12, k = rem - f * 12;
+    float v = 0.f;
+    if (i < 2 * Sh::F * 12) {
+      if (k < 9) v = th[(unsigned)((br ? Sh::oB2w : Sh::oA2w) + f * 9 + k)];
+      else if (k == 9) v = th[(unsigned)((br ? Sh::oB2b : Sh::oA2b) + f)];
+    }
+    preD[q] = v;
+  }
+#pragma unroll
+  for (int q = 0; q < NPRE_W; ++q) {
+    const int i = tid0 + q * Sh::NT;
+    preW[q] = i < kst * Sh::H ? th[(unsigned)(Sh::oFc2w + i)] : 0.f;
+  }
+  if (tid0 < KMAX) preB = tid0 < K ? th[(unsigned)(Sh::oFc2w + K * Sh::H + tid0)] : 0.f;
   if ((MODE == MODE_TRAIN || MODE == MODE_DENSE) && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? a.in.cursor[0] * B : 0;   // epoch-plan offset of this batch
-  __syncthreads();
+  const bool pre_issued = AUX_WAVE && a.in.mode == 1 && (int)blockIdx.x < B;
+  int label0 = 0;                             // (fetched before the gather: a younger load could only be waited for
+  if (MODE == MODE_TRAIN && pre_issued) label0 = a.labels[boff + blockIdx.x];   //  together with the whole window)
+  if (pre_issued) {
+    aux_gather_dma<Sh>(a.in, boff + blockIdx.x, sAux, lane);
+    x_gather_dma<Sh>(a.in, boff + blockIdx.x, sX, wave, lane);
+  }
+#pragma unroll
+  for (int q = 0; q < NPRE_P; ++q) { const int i = tid0 + q * Sh::NT; if (i < Sh::P * L::RS) sPool[i] = preP[q]; }
+#pragma unroll
+  for (int q = 0; q < NPRE_D; ++q) { const int i = tid0 + q * Sh::NT; if (i < 2 * Sh::F * 12) sDww[i] = preD[q]; }
+#pragma unroll
+  for (int q = 0; q < NPRE_W; ++q) { const int i = tid0 + q * Sh::NT; if (i < kst * Sh::H) sW2[i] = preW[q]; }
+  if (tid0 < KMAX) sB2[tid0] = preB;
+  LDS_BARRIER();
+  STAMP(12);
 
   constexpr int N1 = (Sh::F2 + 7) / 8;
   constexpr int NPH = (Sh::P2 + 63) / 64;
-  constexpr bool AUX_WAVE = (Sh::PB * Sh::C2 <= 256);        // small aux tile: every wave loads its own copy
   static_assert(Sh::H == 64, "the single-wave fc2 / softmax / dh step maps lane <-> hidden unit");
 
   bool first = true;
@@ -531,13 +562,16 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     const int pixl = lane;     // lane <-> pixel of a wave-task's 64-pixel half
     int label = 0;             // fetched now, needed in the head
     if (MODE == MODE_TRAIN) {
-      label = a.labels[boff + b];
+      label = (first && pre_issued) ? label0 : a.labels[boff + b];
       label = label < 0 ? 0 : (label >= K ? K - 1 : label);
       label = __builtin_amdgcn_readfirstlane(label);
     }
     // ------------------------------------------------------------------ P0: issue the window gather
     STAMP(0);
     if (a.in.mode == 1) {
+      if (first && pre_issued) {
+        // issued in the prologue
+      } else {
       if (AUX_WAVE) {
         aux_gather_dma<Sh>(a.in, boff + b, sAux, lane);               // every wave fetches its own (identical) copy
       } else {
@@ -545,6 +579,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         __syncthreads();
       }
       x_gather_dma<Sh>(a.in, boff + b, sX, wave, lane);
+      }
       // this wave's aux pieces were issued before its NXW window pieces: they have landed once at most NXW loads
       // are outstanding (vmcnt counts in issue order)
       if (AUX_WAVE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::NXW) : "memory");

@@ -1,15 +1,18 @@
 // dmf_xgmi.h — device side of the one-shot gradient exchange over xGMI (include/dmf.h "dmf_xgmi_*").
 //
-// Memory layout (per rank, both allocated uncached so that remote writes/reads never sit in a local L2):
-//   data  : [region 2][parity 2][cap] float      region 0 = training exchange, 1 = dmf_xgmi_allreduce
+// Memory layout (per rank; both buffers are allocated UNCACHED by their owner, who is the only one that READS them):
+//   data  : [region 2][parity 2][src rank world][cap] float   inbox; region 0 = training exchange, 1 = dmf_xgmi_allreduce
 //   flags : [region 2][src rank world][nblk] int32, then one status word
-// Protocol for block `blk` at sequence number `seq` (monotonic, identical on all ranks):
-//   1. publish own values in data[rank][region][seq&1]                      (system-scope stores)
-//   2. flags[peer][region][rank][blk] = seq on every peer                   (release, system scope)
-//   3. wait until flags[rank][region][peer][blk] >= seq for every peer      (acquire, bounded by a wall-clock timeout)
-//   4. read data[r][region][seq&1] for r = 0..world-1 and add in that order
-// A peer can run at most one sequence number ahead (it needs this rank's flag to finish the next one), which is
-// what the two parities are for.  Blocks never wait for other blocks of the same grid.
+// Protocol for block `blk` at sequence number `seq` (monotonic, identical on all ranks) — a PUSH exchange:
+//   1. write own values into data[r][region][seq&1][rank] of EVERY rank r      (system-scope stores through the IPC mapping)
+//   2. flags[peer][region][rank][blk] = seq on every peer                      (release, system scope)
+//   3. wait until flags[rank][region][peer][blk] >= seq for every peer         (acquire, bounded by a wall-clock timeout)
+//   4. read the world values from the OWN inbox and add them in rank order
+// Reads only ever go to memory the reader allocated itself as uncached, so they can never be served from a stale cache
+// line: an IPC import does not carry the exporter's uncached attribute (a pull over the imported mapping was seen to
+// return a previous round's value once, with all ranks on one GPU).  Writes through the imported mapping are made
+// visible by the system-scope release.  A peer can run at most one sequence number ahead (it needs this rank's flag to
+// finish the next one), which is what the two parities are for.  Blocks never wait for other blocks of the same grid.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,8 +38,13 @@ __host__ __device__ inline int64_t xgmi_status_index(int world, int nblk) { retu
 __device__ __forceinline__ float xgmi_exchange(const XgmiDev& x, int region, int seq, int blk, int64_t idx,
                                                bool valid, float g) {
   const int tid = threadIdx.x;
-  const int64_t slot = ((int64_t)(region * 2 + (seq & 1))) * x.cap + idx;
-  if (valid) __hip_atomic_store(x.data[x.rank] + slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int64_t base = ((int64_t)(region * 2 + (seq & 1))) * x.world * x.cap;
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < XGMI_MAX; ++r)
+      if (r < x.world)
+        __hip_atomic_store(x.data[r] + base + (int64_t)x.rank * x.cap + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __threadfence_system();
   __syncthreads();
   if (tid < x.world && tid != x.rank) {
@@ -58,10 +66,11 @@ __device__ __forceinline__ float xgmi_exchange(const XgmiDev& x, int region, int
   __syncthreads();
   float s = 0.f;
   if (valid) {
+    const float* inbox = x.data[x.rank] + base + idx;
     float v[XGMI_MAX];
 #pragma unroll
     for (int r = 0; r < XGMI_MAX; ++r)
-      v[r] = (r < x.world) ? __hip_atomic_load(x.data[r] + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+      v[r] = (r < x.world) ? __hip_atomic_load(inbox + (int64_t)r * x.cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
 #pragma unroll
     for (int r = 0; r < XGMI_MAX; ++r)
       if (r < x.world) s += v[r];

@@ -1,6 +1,6 @@
 """One-shot gradient exchange between the per-GPU processes of a node (include/dmf.h "dmf_xgmi_*").
 
-Each rank owns two uncached device buffers (published gradients, arrival flags) and maps every peer's pair
+Each rank owns two uncached device buffers (gradient inbox, arrival flags) and maps every peer's pair
 through HIP IPC; the 64-byte handles travel over the torch.distributed group that already exists for the job.
 `create()` verifies the mapping with a known-answer all-reduce against the group's own all_reduce before the
 communicator is handed out; if any rank cannot set it up (IPC refused, a wait timed out, a sum differs) every

@@ -55,6 +55,9 @@ def main():
     for n, c in zip(NAMES, med):
         print('  %-34s %9.0f  %5.1f %%' % (n, c, 100 * c / tot))
     print('  %-34s %9.0f' % ('total', tot))
+    full = stamps.cpu().numpy().reshape(nblk, 16).astype(np.float64)
+    print('  %-34s %9.0f' % ('prologue (kernel entry -> tables in LDS)', np.median(full[:, 12] - full[:, 11])))
+    print('  %-34s %9.0f' % ('kernel entry -> end of patch', np.median(full[:, 10] - full[:, 11])))
     span = (s[:, 10].max() - s[:, 0].min())
     print('first start -> last end across workgroups: %.0f ticks' % span)
 
