@@ -166,7 +166,7 @@ struct AttnTrainLds {
   static constexpr int fZ = 0, fHd = fZ + 80, fLg = fHd + 64, fDl = fLg + 64, fDh = fDl + 64, fDz = fDh + 64,
                        fPw = fDz + 80, fU = fPw + T, fOb = fU + E, fObw = fOb + E, fDzw = fObw + 8 * E,
                        fSt = fDzw + 8 * FO, fA = fSt + 4 * T, fCw = fA + T, fC = fCw + 8 * T,
-                       fG = fC + T, fBb = fG + FO, FLOATS = fBb + FO;
+                       fG = fC + T, FLOATS = fG + FO;
   static constexpr int WPREP = 3 * DH * WS + 3 * FO * OS;      // one head's weights: Wq Wk Wv [DH][WS], WqT WkT Wo [FO][OS]
   static_assert(oWo + FO * OS - oWq == WPREP && WPREP % 8 == 0 && oWq % 8 == 0, "weights are one contiguous LDS block");
   static constexpr size_t BYTES = (size_t)HALVES * 2 + (size_t)FLOATS * 4;
@@ -218,7 +218,6 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #define sCw AT_F(L::fCw)
 #define sC AT_F(L::fC)
 #define sG AT_F(L::fG)
-#define sBb AT_F(L::fBb)
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);

@@ -313,7 +313,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
                      int32_t* pred, void* workspace, int32_t* adam_step, void* stream) {
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr) return fail("%s", "null argument");
   if (dmf_shape_supported(s)) return 1;
-  if (s->attention && mode != MODE_FWD) return fail("%s", "training with the attention block is not built yet (forward only)");
+  if (s->attention) return fail("%s", "attention network: use dmf_forward_attn / dmf_train_attn_fwd_bwd");
   if (in->B < 0) return fail("%s", "negative batch");
   if (in->B == 0) return 0;
   if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");

@@ -193,6 +193,9 @@ class EvalEngine:
         K = net.arch['K']
         self.logits = torch.empty(self.B, K, device=dev)
         self.pred = torch.empty(self.B, dtype=torch.int32, device=dev)
+        self.attn_ws = None
+        if self.shape.attention:
+            self.attn_ws = torch.empty(lib.attn_workspace_bytes(self.shape, self.B), dtype=torch.uint8, device=dev)
 
     def predict(self, xy):
         """xy [n,2] int32 device -> (logits [n,K], pred [n]) views valid until the next call."""
@@ -200,7 +203,10 @@ class EvalEngine:
         if n > self.B:
             raise lib.DmfError('batch larger than the engine was built for')
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
-        lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits, self.pred)
+        if self.shape.attention:
+            lib.forward_attn(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.attn_ws, self.logits, self.pred)
+        else:
+            lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits, self.pred)
         return self.logits[:n], self.pred[:n]
 
     def confusion(self, xy_all, labels_all, matrix=None):

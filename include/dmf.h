@@ -87,7 +87,7 @@ int32_t dmf_forward(const dmf_shape* shape, const dmf_input* in, const float* th
 /* Forward of the network WITH the cross-modal attention block (shape->attention == 1; BASELINE configs[2]):
  * the conv stages emit bf16 token maps, then a matrix-core kernel (bf16 MFMA operands, fp32 accumulate) does the
  * projections, Q K^T, softmax, P V, the output projection, the pooling correction and the head.
- * `workspace` needs dmf_attn_workspace_bytes(shape, B) bytes.  Training with attention is not built yet. */
+ * `workspace` needs dmf_attn_workspace_bytes(shape, B) bytes.  Training: dmf_train_attn_fwd_bwd below. */
 int64_t dmf_attn_workspace_bytes(const dmf_shape* shape, int32_t B);
 int32_t dmf_forward_attn(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                          void* workspace, float* logits, int32_t* pred, void* stream);
