@@ -25,37 +25,40 @@ struct QuaArgs {
 
 constexpr int QT = 1024;
 
+// sum of N per-thread values over the 1024-thread block, result in every thread: butterfly inside each wavefront,
+// then the 16 wave sums in fixed order through LDS (two barriers for all N values; the order never depends on timing)
 template <int N>
-__device__ __forceinline__ void block_sum(float (&v)[N], float* red) {   // fixed tree; result in every thread
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    red[tid] = v[j];
-    __syncthreads();
-    for (int w = QT / 2; w > 0; w >>= 1) {
-      if (tid < w) red[tid] += red[tid + w];
-      __syncthreads();
-    }
-    v[j] = red[0];
-    __syncthreads();
+    float x = v[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) red[wave * N + j] = x;
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float x = 0.f;
+#pragma unroll
+    for (int w = 0; w < QT / 64; ++w) x += red[w * N + j];
+    v[j] = x;
+  }
+  __syncthreads();
 }
 
-struct Row { float mx, inv; };   // softmax row statistics: p_k = exp(x_k - mx) * inv
-
-__device__ __forceinline__ Row row_stats(const float* x, int K) {
-  float mx = x[0];
-  for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
-  float s = 0.f;
-  for (int k = 0; k < K; ++k) s += expf(x[k] - mx);
-  return Row{mx, 1.f / s};
-}
-__device__ __forceinline__ float prob(const float* x, int k, const Row& r) { return expf(x[k] - r.mx) * r.inv; }
 __device__ __forceinline__ float xlogx(float y) { return y > 0.f ? y * logf(y) : 0.f; }
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a) {
-  __shared__ float red[QT];
+// The batch is walked in tiles of TS samples whose 4*TS softmax rows live in LDS (sP[stream][sample][k]); within a
+// tile all 1024 threads work: one softmax row each, then thread <-> (sample, quarter) for the sums and
+// thread <-> (sample, stream) for the gradient rows.  A batch that fits one tile (bs <= TS, e.g. 256 x 17 logits)
+// computes its probabilities once; larger batches recompute them per sweep.
+__global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a, const int TS) {
+  extern __shared__ __attribute__((aligned(16))) float sdyn[];
+  float* red = sdyn;                    // [QT]
+  float* sP = sdyn + QT;                // [4][TS][K]
   const int tid = threadIdx.x, bs = a.bs, K = a.K;
   const int cur = a.cursor != nullptr ? *a.cursor : 0;
   const int32_t* lab = a.labels + (size_t)cur * bs;
@@ -63,30 +66,57 @@ __global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a) {
   const float e1 = expf(-1.f);
   const float lsum = 1.f + (float)(K - 1) * e1;          // softmax of a one-hot row (loss_function.py:52)
   const float l_hit = 1.f / lsum, l_miss = e1 / lsum;
+  const int ntile = (bs + TS - 1) / TS;
+  const bool one_tile = ntile == 1;
 
-  // ---- pass 1
+  // softmax rows of tile `t0..t0+nt` -> sP
+  auto fill = [&](int t0, int nt) {
+    for (int row = tid; row < 4 * nt; row += QT) {
+      const int st = row / nt, i = row - st * nt;
+      const float* x = a.logits + ((size_t)st * bs + t0 + i) * K;
+      float mx = x[0];
+      for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+      float sum = 0.f;
+      for (int k = 0; k < K; ++k) sum += expf(x[k] - mx);
+      const float inv = 1.f / sum;
+      float* o = sP + ((size_t)st * TS + i) * K;
+      for (int k = 0; k < K; ++k) o[k] = expf(x[k] - mx) * inv;
+    }
+    __syncthreads();
+  };
+
+  // ---- sweep 1: the six KL sums and the class term.  thread <-> (sample i, quarter j):
+  //      j = 0: A1 = D(q>p), A2 = D(r>p)   j = 1: A3 = D(s>p), l4   j = 2: B1 = D(p>q), B2 = D(r>q)   j = 3: B3 = D(s>q)
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < bs; i += QT) {
-    const float* xp = a.logits + (size_t)i * K;
-    const float* xq = xp + (size_t)bs * K;
-    const float* xr = xq + (size_t)bs * K;
-    const float* xs = xr + (size_t)bs * K;
-    const Row rp = row_stats(xp, K), rq = row_stats(xq, K), rr = row_stats(xr, K), rs = row_stats(xs, K);
-    float zmx = -INFINITY;
-    for (int k = 0; k < K; ++k) zmx = fmaxf(zmx, prob(xp, k, rp) + prob(xq, k, rq));
-    float zs = 0.f;
-    for (int k = 0; k < K; ++k) zs += expf(prob(xp, k, rp) + prob(xq, k, rq) - zmx);
-    const float lzs = logf(zs);
-    const int t = lab[i];
-    for (int k = 0; k < K; ++k) {
-      const float p = prob(xp, k, rp), q = prob(xq, k, rq), r = prob(xr, k, rr), s = prob(xs, k, rs);
-      const float lq = logf(q + a.eps), lp = logf(p + a.eps), lr = logf(r + a.eps), ls = logf(s + a.eps);
-      const float plp = xlogx(p), qlq = xlogx(q);
-      acc[0] += plp - p * lq;  acc[1] += plp - p * lr;  acc[2] += plp - p * ls;
-      acc[3] += qlq - q * lp;  acc[4] += qlq - q * lr;  acc[5] += qlq - q * ls;
-      const float l = (k == t) ? l_hit : l_miss;
-      const float logm = (p + q - zmx) - lzs;              // log softmax(p + q)
-      acc[6] += l * (logf(l) - logm);
+  for (int t = 0; t < ntile; ++t) {
+    const int t0 = t * TS, nt = min(TS, bs - t0);
+    if (t > 0) __syncthreads();
+    fill(t0, nt);
+    for (int w = tid; w < 4 * nt; w += QT) {
+      const int j = w / nt, i = w - j * nt;
+      const float* p = sP + (size_t)i * K;
+      const float* q = p + (size_t)TS * K;
+      const float* r = q + (size_t)TS * K;
+      const float* s = r + (size_t)TS * K;
+      if (j == 0) {
+        for (int k = 0; k < K; ++k) { const float pl = xlogx(p[k]); acc[0] += pl - p[k] * logf(q[k] + a.eps); acc[1] += pl - p[k] * logf(r[k] + a.eps); }
+      } else if (j == 1) {
+        float zmx = -INFINITY;
+        for (int k = 0; k < K; ++k) zmx = fmaxf(zmx, p[k] + q[k]);
+        float zs = 0.f;
+        for (int k = 0; k < K; ++k) zs += expf(p[k] + q[k] - zmx);
+        const float lzs = logf(zs);
+        const int tg = lab[t0 + i];
+        for (int k = 0; k < K; ++k) {
+          acc[2] += xlogx(p[k]) - p[k] * logf(s[k] + a.eps);
+          const float l = (k == tg) ? l_hit : l_miss;
+          acc[6] += l * (logf(l) - ((p[k] + q[k] - zmx) - lzs));        // log softmax(p + q)
+        }
+      } else if (j == 2) {
+        for (int k = 0; k < K; ++k) { const float ql = xlogx(q[k]); acc[3] += ql - q[k] * logf(p[k] + a.eps); acc[4] += ql - q[k] * logf(r[k] + a.eps); }
+      } else {
+        for (int k = 0; k < K; ++k) acc[5] += xlogx(q[k]) - q[k] * logf(s[k] + a.eps);
+      }
     }
   }
   block_sum(acc, red);
@@ -95,25 +125,29 @@ __global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a) {
   const float d1 = A3 - A2 + a.tao, d2 = B3 - B2 + a.tao;
   const float l12 = (A1 + A2 + fabsf(d1)) + (B1 + B2 + fabsf(d2));
 
-  // ---- pass 2
+  // ---- sweep 2: l3 = mean_ik exp(-|A3/p|) + exp(-|B3/q|) and dl3/dA3, dl3/dB3.  thread <-> (sample, p or q)
   float l3 = 0.f, GA = 0.f, GB = 0.f;
+  const float inv_nk = 1.f / ((float)bs * (float)K);
   if (a.beta != 0.f) {
     float b3[3] = {0.f, 0.f, 0.f};
-    for (int i = tid; i < bs; i += QT) {
-      const float* xp = a.logits + (size_t)i * K;
-      const float* xq = xp + (size_t)bs * K;
-      const Row rp = row_stats(xp, K), rq = row_stats(xq, K);
-      for (int k = 0; k < K; ++k) {
-        const float p = prob(xp, k, rp), q = prob(xq, k, rq);
-        const float ua = A3 / p, ub = B3 / q;
-        const float fa = expf(-fabsf(ua)), fb = expf(-fabsf(ub));
-        b3[0] += fa + fb;
-        b3[1] += (p > 0.f) ? -sgn(ua) * fa / p : 0.f;
-        b3[2] += (q > 0.f) ? -sgn(ub) * fb / q : 0.f;
+    for (int t = 0; t < ntile; ++t) {
+      const int t0 = t * TS, nt = min(TS, bs - t0);
+      if (!one_tile) { __syncthreads(); fill(t0, nt); }
+      for (int w = tid; w < 2 * nt; w += QT) {
+        const int j = w / nt, i = w - j * nt;
+        const float* y = sP + ((size_t)j * TS + i) * K;
+        const float c = j == 0 ? A3 : B3;
+        float f = 0.f, gsum = 0.f;
+        for (int k = 0; k < K; ++k) {
+          const float u = c / y[k], e = expf(-fabsf(u));
+          f += e;
+          gsum += (y[k] > 0.f) ? -sgn(u) * e / y[k] : 0.f;
+        }
+        b3[0] += f;
+        b3[1 + j] += gsum;
       }
     }
     block_sum(b3, red);
-    const float inv_nk = 1.f / ((float)bs * (float)K);
     l3 = b3[0] * inv_nk; GA = b3[1] * inv_nk; GB = b3[2] * inv_nk;
   }
   const float loss = (a.alpha != 0.f ? a.alpha * l12 : 0.f) + a.beta * l3 + a.gamma * l4;
@@ -123,64 +157,72 @@ __global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a) {
   }
   if (a.dlogits == nullptr) return;
 
-  // ---- pass 3
+  // ---- sweep 3: d loss / d probabilities of the four streams, through the four softmaxes.
+  //      thread <-> (sample, stream): first the row's inner product sum_k dProb_k prob_k, then the gradient row
   const float s1 = sgn(d1), s2 = sgn(d2);
   const float al = a.alpha;
   const float cA1 = al, cA2 = al * (1.f - s1), cA3 = al * s1 + a.beta * GA;
   const float cB1 = al, cB2 = al * (1.f - s2), cB3 = al * s2 + a.beta * GB;
-  const float inv_nk = 1.f / ((float)bs * (float)K);
-  for (int i = tid; i < bs; i += QT) {
-    const float* xp = a.logits + (size_t)i * K;
-    const float* xq = xp + (size_t)bs * K;
-    const float* xr = xq + (size_t)bs * K;
-    const float* xs = xr + (size_t)bs * K;
-    float* gp = a.dlogits + (size_t)i * K;
-    float* gq = gp + (size_t)bs * K;
-    float* gr = gq + (size_t)bs * K;
-    float* gs = gr + (size_t)bs * K;
-    const Row rp = row_stats(xp, K), rq = row_stats(xq, K), rr = row_stats(xr, K), rs = row_stats(xs, K);
-    float zmx = -INFINITY;
-    for (int k = 0; k < K; ++k) zmx = fmaxf(zmx, prob(xp, k, rp) + prob(xq, k, rq));
-    float zs = 0.f;
-    for (int k = 0; k < K; ++k) zs += expf(prob(xp, k, rp) + prob(xq, k, rq) - zmx);
-    const float zinv = 1.f / zs;
-    const int t = lab[i];
-    // two sweeps over k: first the inner products  sum_k dProb_k * prob_k  of the four rows, then the gradients
-    float ip = 0.f, iq = 0.f, ir = 0.f, is = 0.f;
-#pragma unroll 1
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      for (int k = 0; k < K; ++k) {
-        const float p = prob(xp, k, rp), q = prob(xq, k, rq), r = prob(xr, k, rr), s = prob(xs, k, rs);
-        const float l = (k == t) ? l_hit : l_miss;
-        const float m = expf(p + q - zmx) * zinv;
-        const float dz = a.gamma * inv_n * (m - l);          // sum_k l == 1 up to rounding
-        const float logp1 = (p > 0.f) ? logf(p) + 1.f : 0.f, logq1 = (q > 0.f) ? logf(q) + 1.f : 0.f;
-        float dP = inv_n * (cA1 * (logp1 - logf(q + a.eps)) + cA2 * (logp1 - logf(r + a.eps)) + cA3 * (logp1 - logf(s + a.eps)))
-                   - inv_n * cB1 * q / (p + a.eps) + dz;
-        float dQ = inv_n * (cB1 * (logq1 - logf(p + a.eps)) + cB2 * (logq1 - logf(r + a.eps)) + cB3 * (logq1 - logf(s + a.eps)))
-                   - inv_n * cA1 * p / (q + a.eps) + dz;
-        if (a.beta != 0.f) {
-          const float ua = A3 / p, ub = B3 / q;
-          if (p > 0.f) dP += a.beta * inv_nk * sgn(ua) * expf(-fabsf(ua)) * A3 / (p * p);
-          if (q > 0.f) dQ += a.beta * inv_nk * sgn(ub) * expf(-fabsf(ub)) * B3 / (q * q);
-        }
-        const float dR = -inv_n * (cA2 * p + cB2 * q) / (r + a.eps);
-        const float dS = -inv_n * (cA3 * p + cB3 * q) / (s + a.eps);
-        if (sweep == 0) {
-          ip += dP * p; iq += dQ * q; ir += dR * r; is += dS * s;
-        } else {
-          gp[k] = a.grad_scale * p * (dP - ip);
-          gq[k] = a.grad_scale * q * (dQ - iq);
-          gr[k] = a.grad_scale * r * (dR - ir);
-          gs[k] = a.grad_scale * s * (dS - is);
-        }
+  for (int t = 0; t < ntile; ++t) {
+    const int t0 = t * TS, nt = min(TS, bs - t0);
+    if (!one_tile) { __syncthreads(); fill(t0, nt); }
+    for (int w = tid; w < 4 * nt; w += QT) {
+      const int st = w / nt, i = w - st * nt;
+      const float* p = sP + (size_t)i * K;
+      const float* q = p + (size_t)TS * K;
+      const float* r = q + (size_t)TS * K;
+      const float* s = r + (size_t)TS * K;
+      float zmx = 0.f, zinv = 0.f;
+      const int tg = lab[t0 + i];
+      if (st < 2) {
+        zmx = -INFINITY;
+        for (int k = 0; k < K; ++k) zmx = fmaxf(zmx, p[k] + q[k]);
+        float zs = 0.f;
+        for (int k = 0; k < K; ++k) zs += expf(p[k] + q[k] - zmx);
+        zinv = 1.f / zs;
       }
+      // dProb of this thread's row at class k
+      auto dprob = [&](int k) -> float {
+        const float pk = p[k], qk = q[k], rk = r[k], sk = s[k];
+        if (st == 2) return -inv_n * (cA2 * pk + cB2 * qk) / (rk + a.eps);
+        if (st == 3) return -inv_n * (cA3 * pk + cB3 * qk) / (sk + a.eps);
+        const float l = (k == tg) ? l_hit : l_miss;
+        const float dz = a.gamma * inv_n * (expf(pk + qk - zmx) * zinv - l);     // sum_k l == 1 up to rounding
+        const float lr = logf(rk + a.eps), ls = logf(sk + a.eps);
+        if (st == 0) {
+          const float lg1 = (pk > 0.f) ? logf(pk) + 1.f : 0.f;
+          float d = inv_n * (cA1 * (lg1 - logf(qk + a.eps)) + cA2 * (lg1 - lr) + cA3 * (lg1 - ls)) - inv_n * cB1 * qk / (pk + a.eps) + dz;
+          if (a.beta != 0.f && pk > 0.f) { const float u = A3 / pk; d += a.beta * inv_nk * sgn(u) * expf(-fabsf(u)) * A3 / (pk * pk); }
+          return d;
+        }
+        const float lg1 = (qk > 0.f) ? logf(qk) + 1.f : 0.f;
+        float d = inv_n * (cB1 * (lg1 - logf(pk + a.eps)) + cB2 * (lg1 - lr) + cB3 * (lg1 - ls)) - inv_n * cA1 * pk / (qk + a.eps) + dz;
+        if (a.beta != 0.f && qk > 0.f) { const float u = B3 / qk; d += a.beta * inv_nk * sgn(u) * expf(-fabsf(u)) * B3 / (qk * qk); }
+        return d;
+      };
+      const float* y = sP + ((size_t)st * TS + i) * K;
+      float* g = a.dlogits + ((size_t)st * bs + t0 + i) * K;
+      float ip = 0.f;
+      for (int k = 0; k < K; ++k) { const float d = dprob(k); g[k] = d; ip += d * y[k]; }     // (row parked in its output)
+      for (int k = 0; k < K; ++k) g[k] = a.grad_scale * y[k] * (g[k] - ip);
     }
   }
 }
 
 hipError_t launch_qua_loss(const QuaArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(qua_loss_kernel, dim3(1), dim3(QT), 0, st, a);
+  // tile: as many samples as fit ~128 KB of probabilities, at most 256 (4 rows x 256 = one row per thread)
+  int ts = (128 * 1024 / 4) / (4 * a.K);
+  ts = ts > 256 ? 256 : (ts < 1 ? 1 : ts);
+  if (ts > a.bs) ts = a.bs;
+  const size_t bytes = (size_t)(QT + 4 * ts * a.K) * sizeof(float);
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qua_loss_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL(qua_loss_kernel, dim3(1), dim3(QT), bytes, st, a, ts);
   return hipGetLastError();
 }
 
