@@ -368,6 +368,13 @@ __device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>:
   }
 }
 
+// x if bit c of the row mask is set, else +0: one signed 1-bit field extract (0 / -1) and one AND instead of the
+// and + compare + select the ?: form compiles to
+__device__ __forceinline__ float keep_if_bit(float x, uint32_t mask, int c) {
+  const int t = __builtin_amdgcn_sbfe((int)mask, c, 1);
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & t);
+}
+
 // backward pass 1 of one branch: dW[u][v] += dY2(r,c) * Y1(r+u-1, c+v-1), db += dY2(r,c),
 // with dY2(r,c) = mask(r,c) ? dz * pool[r,c] : 0
 //   (DENSE: dY2(r,c) = mask(r,c) ? dd[r*P + c] : 0, dd = this channel's dense gradient map in global memory)
@@ -386,7 +393,7 @@ __device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh
   db = 0.f;
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    const float d2 = ((mr >> c) & 1u) ? (DENSE ? dd[r * Sh::P + c] : dz * pw[c]) : 0.f;
+    const float d2 = keep_if_bit(DENSE ? dd[r * Sh::P + c] : dz * pw[c], mr, c);
     db += d2;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -416,7 +423,7 @@ __device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const u
     load_row<Sh>(sPool + (in ? rr : r) * L::RS, pw);
 #pragma unroll
     for (int c = 0; c < Sh::P; ++c)
-      g[u][c] = ((mm >> c) & 1u) ? (DENSE ? dd[(in ? rr : r) * Sh::P + c] : dz * pw[c]) : 0.f;
+      g[u][c] = keep_if_bit(DENSE ? dd[(in ? rr : r) * Sh::P + c] : dz * pw[c], mm, c);
   }
   float y1[L::RS];
   float* row = sY + f * L::FSZ + r * L::RS;
