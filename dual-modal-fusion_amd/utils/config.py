@@ -22,57 +22,72 @@ def get_config(path):
         return yaml.safe_load(f)
 
 
+def _template_values(raw):
+    """Values the YAML file refers to as {{name}} (reference: utils/config.py:20-35)."""
+    city = raw['data_city']
+    stage = raw.get('dqtl') or {}
+    return dict(
+        parameter1='value1', p2=Path(__file__).resolve().parent.parent, dc=city,
+        num=len(raw['DATA_DICT'][city]['color']),                 # colours incl. the background class 0 (:25)
+        tr=raw['train_rate'], ep=raw['epoch'], bs=raw['batchsize'],
+        expo_result=raw['expo_result'], parameters=raw['parameters'], mn=raw['model_name'], FN=raw['FILE_NUM'],
+        ne=stage.get('num_epochs', 0), ps=stage.get('pic_size', 0))
+
+
 def get_render_config(path):
-    data = get_config(path)
-    base_dir = Path(__file__).resolve().parent.parent
+    raw = get_config(path)
     with open(path, 'r', encoding='utf-8') as f:
-        template = Template(f.read())
-    dqtl = data.get('dqtl') or {}
-    parameters = {
-        'parameter1': 'value1', 'p2': base_dir, 'dc': data['data_city'],
-        'num': len(data['DATA_DICT'][data['data_city']]['color']),      # incl. background class 0 (:25)
-        'tr': data['train_rate'], 'ep': data['epoch'], 'bs': data['batchsize'],
-        'expo_result': data['expo_result'], 'parameters': data['parameters'],
-        'mn': data['model_name'], 'FN': data['FILE_NUM'],
-        'ne': dqtl.get('num_epochs', 0), 'ps': dqtl.get('pic_size', 0),
-    }
-    y = yaml.safe_load(template.render(**parameters))
-    return get_dump_config(y)
+        rendered = Template(f.read()).render(**_template_values(raw))
+    return get_dump_config(yaml.safe_load(rendered))
+
+
+class _RunSlots:
+    """Numbered result slots `<RESULT><model>__<n>_result.xlsx` / `<RESULT><model>__<n>_output/` (:44-77)."""
+
+    def __init__(self, cfg):
+        self.stem = cfg['RESULT'] + cfg['model_name'] + '__'
+
+    def sheet(self, n):
+        return '%s%d_result.xlsx' % (self.stem, n)
+
+    def folder(self, n):
+        return '%s%d_output/' % (self.stem, n)
+
+    def taken(self, n):
+        return os.path.exists(self.sheet(n)) or os.path.exists(self.folder(n))
+
+    def first_free(self):
+        n = 0
+        while self.taken(n):
+            n += 1
+        return n
 
 
 def get_dump_config(y):
     os.makedirs(y['RESULT'], exist_ok=True)
-
-    def names(n):
-        stem = y['RESULT'] + y['model_name'] + "__" + str(n)
-        return stem + '_result.xlsx', stem + '_output/'
-
-    filenum = 0
-    result_excel, result_output = names(filenum)
-    if not y['train']['index'] == 0:
-        while os.path.exists(result_excel) or os.path.exists(result_output):
-            filenum += 1
-            result_excel, result_output = names(filenum)
-        y['FILE_NUM'] = filenum
+    slots = _RunSlots(y)
+    if y['train']['index'] != 0:
+        probe = slot = slots.first_free()
         if y.get('delete'):
-            for num in range(filenum - 1, -1, -1):
-                xlsx, out_dir = names(num)
-                if os.path.isdir(out_dir) and not os.path.isfile(xlsx):
-                    shutil.rmtree(out_dir)
-                    filenum = num
-                    y['FILE_NUM'] = filenum
+            # an output folder without its result sheet is an aborted run: drop it and reuse the lowest such number
+            for n in reversed(range(slot)):
+                if os.path.isdir(slots.folder(n)) and not os.path.isfile(slots.sheet(n)):
+                    shutil.rmtree(slots.folder(n))
+                    slot = n
+        y['FILE_NUM'] = slot
     else:
-        filenum = y['FILE_NUM']
-    y['RESULT_excel'] = result_excel                        # as the reference: the name probed last (:77)
-    y['RESULT_output'] = names(filenum)[1]
-    y['schedule']['lr'] = float(y['schedule']['lr'])
-    y['schedule']['base_lr'] = float(y['schedule']['base_lr'])
+        probe = 0
+        slot = y['FILE_NUM']
+    y['RESULT_excel'] = slots.sheet(probe)                  # as the reference: the name probed last (:77)
+    y['RESULT_output'] = slots.folder(slot)
+    for key in ('lr', 'base_lr'):
+        y['schedule'][key] = float(y['schedule'][key])
     y['Categories_Number'] = int(y['Categories_Number'])
-    if y.get('dqtl'):
-        for k in ('lr', 'tao', 'epsilon'):
-            if k in y['dqtl']:
-                y['dqtl'][k] = float(y['dqtl'][k])
+    stage = y.get('dqtl') or {}
+    for key in ('lr', 'tao', 'epsilon'):
+        if key in stage:
+            stage[key] = float(stage[key])
     y = yaml.safe_load(yaml.dump(y))
-    if not os.path.exists(y['RESULT_output']) and y['train']['save_best']:
+    if y['train']['save_best'] and not os.path.exists(y['RESULT_output']):
         os.makedirs(y['RESULT_output'])
     return y

@@ -1,116 +1,138 @@
 """utils.utils — optimiser / loss / scheduler factories and checkpoint helpers (mirror of the reference module).
 
-`make_optimizer`, `make_loss`, `make_scheduler` build the same torch objects from the same cfg keys as the
-reference (utils/utils.py:8-71): ADAM = `torch.optim.Adam(params, lr)` with every other default, `Criterion` =
-`nn.CrossEntropyLoss()`, the eight scheduler kinds.  They serve the drop-in path in which the reference-style
-solver loop drives `model.gmfnet.Net` through autograd; the resident-scene fast path (dmf/engine.py) applies the
-same Adam update in `dmf_grad_reduce_adam` and takes only the hyper-parameters from here (`adam_hparams`).
-Checkpoint file formats are the reference's (:82-111): `{'state_dict', 'optimizer'}`.
+The three factories return the torch objects the reference builds from the same cfg keys (utils/utils.py:8-71):
+`ADAM` is `torch.optim.Adam(params, lr)` with every other default, `Criterion` is `nn.CrossEntropyLoss()`, and the eight
+scheduler kinds keep the reference's constants.  Here they are lookup tables of small constructors rather than
+if-chains.  They serve the drop-in path (reference-style loop -> `model.gmfnet.Net` -> autograd); the resident-scene
+fast path (dmf/engine.py) applies the same ADAM update inside `dmf_grad_reduce_adam` and takes only the hyper-parameters
+from here (`adam_hparams`, `epoch_lr`).  Checkpoints keep the reference's layout (:82-111): `{'state_dict', 'optimizer'}`.
 """
 import os
 import random
 
 import numpy as np
 import torch
-import torch.nn as nn
-import torch.optim.lr_scheduler as lr_scheduler
+from torch import nn
+from torch.optim import lr_scheduler as _sched
+
+_ADAM_DEFAULTS = ((0.9, 0.999), 1e-8)          # betas, eps of torch.optim.Adam — the reference passes lr only (:12)
+
+_OPTIMIZERS = {
+    'ADAM': lambda s, params: torch.optim.Adam(params, lr=s['lr']),
+    'SGD': lambda s, params: torch.optim.SGD(params, lr=s['lr'], momentum=s['momentum']),
+    'RMSprop': lambda s, params: torch.optim.RMSprop(params, lr=s['lr'], alpha=s['alpha']),
+}
+
+
+def _qua():
+    from train.loss_function import qua_loss      # imported late: it binds the HIP library
+    return qua_loss()
+
+
+_LOSSES = {
+    'MSE': lambda: nn.MSELoss(reduction='mean'),
+    'L1': lambda: nn.L1Loss(reduction='mean'),
+    'Criterion': nn.CrossEntropyLoss,
+    'KL': lambda: nn.KLDivLoss(reduction='batchmean'),
+    'qua_loss': _qua,
+}
+
+
+def _warmup(opt):
+    return _sched.LinearLR(opt, start_factor=0.1, end_factor=1, total_iters=10)
+
+
+def _decay(opt):
+    return _sched.ExponentialLR(optimizer=opt, gamma=0.98)
+
+
+# every entry: (optimizer, cfg['schedule'], cfg) -> scheduler; `ratio` = base_lr / lr as the reference forms it
+_SCHEDULERS = {
+    'StepLR': lambda o, s, c: _sched.StepLR(o, step_size=50, gamma=s['base_lr'] / s['lr']),
+    'LinearLR': lambda o, s, c: _warmup(o),
+    'CosineAnnealingLR': lambda o, s, c: _sched.CosineAnnealingLR(o, 50, s['base_lr']),
+    'CyclicLR': lambda o, s, c: _sched.CyclicLR(o, base_lr=s['base_lr'], max_lr=s['lr'], step_size_up=10,
+                                                step_size_down=40, cycle_momentum=False),
+    'OneCycleLR': lambda o, s, c: _sched.OneCycleLR(o, max_lr=s['lr'], pct_start=0.5, total_steps=c['epoch'],
+                                                    div_factor=s['lr'] / s['base_lr'],
+                                                    final_div_factor=s['lr'] / s['base_lr']),
+    'ConstantLR': lambda o, s, c: _sched.ConstantLR(o, factor=s['base_lr'] / s['lr'], total_iters=10),
+    'ChainedScheduler': lambda o, s, c: _sched.ChainedScheduler([_warmup(o), _decay(o)]),
+    'ExponentialLR': lambda o, s, c: _decay(o),
+}
+
+
+def _pick(table, key, what):
+    try:
+        return table[key]
+    except KeyError:
+        raise ValueError('%s %r is not one of %s' % (what, key, sorted(table))) from None
 
 
 def make_optimizer(cfg, params):
-    opt_type = cfg['schedule']['optimizer']
-    if opt_type == "ADAM":
-        return torch.optim.Adam(params, lr=cfg['schedule']['lr'])
-    if opt_type == "SGD":
-        return torch.optim.SGD(params, lr=cfg['schedule']['lr'], momentum=cfg['schedule']['momentum'])
-    if opt_type == "RMSprop":
-        return torch.optim.RMSprop(params, lr=cfg['schedule']['lr'], alpha=cfg['schedule']['alpha'])
-    raise ValueError(opt_type)
+    return _pick(_OPTIMIZERS, cfg['schedule']['optimizer'], 'optimizer')(cfg['schedule'], params)
+
+
+def make_loss(loss_type, cfg):
+    return _pick(_LOSSES, loss_type, 'loss')()
+
+
+def make_scheduler(optimizer, cfg):
+    s = cfg['schedule']
+    if not s['if_scheduler']:
+        return None
+    return _pick(_SCHEDULERS, s['scheduler'], 'scheduler')(optimizer, s, cfg)
 
 
 def adam_hparams(cfg):
     """(lr, betas, eps) of the ADAM the reference constructs: lr from cfg, torch defaults otherwise."""
-    if cfg['schedule']['optimizer'] != "ADAM":
+    if cfg['schedule']['optimizer'] != 'ADAM':
         raise ValueError('the fused HIP step implements ADAM only; got %s' % cfg['schedule']['optimizer'])
-    return float(cfg['schedule']['lr']), (0.9, 0.999), 1e-8
-
-
-def make_loss(loss_type, cfg):
-    if loss_type == "MSE":
-        return nn.MSELoss(reduction='mean')
-    if loss_type == "L1":
-        return nn.L1Loss(reduction='mean')
-    if loss_type == "Criterion":
-        return nn.CrossEntropyLoss()
-    if loss_type == "KL":
-        return nn.KLDivLoss(reduction='batchmean')
-    if loss_type == 'qua_loss':
-        from train.loss_function import qua_loss
-        return qua_loss()
-    raise ValueError(loss_type)
-
-
-def make_scheduler(optimizer, cfg):
-    sch = cfg['schedule']
-    if not sch['if_scheduler']:
-        return None
-    kind = sch['scheduler']
-    if kind == "StepLR":
-        return lr_scheduler.StepLR(optimizer, step_size=50, gamma=sch['base_lr'] / sch['lr'])
-    if kind == "LinearLR":
-        return lr_scheduler.LinearLR(optimizer, start_factor=0.1, end_factor=1, total_iters=10)
-    if kind == "CosineAnnealingLR":
-        return lr_scheduler.CosineAnnealingLR(optimizer, 50, sch['base_lr'])
-    if kind == "CyclicLR":
-        return lr_scheduler.CyclicLR(optimizer, base_lr=sch['base_lr'], max_lr=sch['lr'], step_size_up=10,
-                                     step_size_down=40, cycle_momentum=False)
-    if kind == "OneCycleLR":
-        return lr_scheduler.OneCycleLR(optimizer, max_lr=sch['lr'], pct_start=0.5, total_steps=cfg['epoch'],
-                                       div_factor=sch['lr'] / sch['base_lr'], final_div_factor=sch['lr'] / sch['base_lr'])
-    if kind == "ConstantLR":
-        return lr_scheduler.ConstantLR(optimizer, factor=sch['base_lr'] / sch['lr'], total_iters=10)
-    if kind == "ChainedScheduler":
-        return lr_scheduler.ChainedScheduler([lr_scheduler.LinearLR(optimizer, start_factor=0.1, end_factor=1, total_iters=10),
-                                              lr_scheduler.ExponentialLR(optimizer, gamma=0.98)])
-    if kind == "ExponentialLR":
-        return lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=0.98)
-    raise ValueError(kind)
+    return (float(cfg['schedule']['lr']),) + _ADAM_DEFAULTS
 
 
 def epoch_lr(cfg, epoch):
-    """Learning rate the reference's scheduler yields after `epoch` scheduler steps, for the fused step
-    (ExponentialLR only; other kinds go through the torch optimiser of the drop-in path)."""
-    sch = cfg['schedule']
-    if not sch['if_scheduler']:
-        return float(sch['lr'])
-    if sch['scheduler'] != 'ExponentialLR':
-        raise ValueError('the fused HIP step supports ExponentialLR only; got %s' % sch['scheduler'])
-    return float(sch['lr']) * 0.98 ** epoch
+    """Learning rate after `epoch` scheduler steps, for the fused step (ExponentialLR only; the other kinds run through
+    the torch optimiser of the drop-in path)."""
+    s = cfg['schedule']
+    if not s['if_scheduler']:
+        return float(s['lr'])
+    if s['scheduler'] != 'ExponentialLR':
+        raise ValueError('the fused HIP step supports ExponentialLR only; got %s' % s['scheduler'])
+    return float(s['lr']) * 0.98 ** epoch
 
 
-def save_point_sche(model, optimizer, schedule, filename="my_checkpoint.pth.tar"):
-    torch.save({"state_dict": model.state_dict(), "optimizer": optimizer.state_dict(),
-                "schedule": schedule.state_dict()}, filename)
+# ---------------------------------------------------------------------------------------------- checkpoints
+def _bundle(model, optimizer, **extra):
+    d = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}
+    d.update(extra)
+    return d
 
 
-def save_checkpoint(model, optimizer, filename="my_checkpoint.pth.tar"):
-    torch.save({"state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}, filename)
+def save_checkpoint(model, optimizer, filename='my_checkpoint.pth.tar'):
+    torch.save(_bundle(model, optimizer), filename)
 
 
-def load_checkpoint(checkpoint_file, model, optimizer, lr, device):
-    checkpoint = torch.load(checkpoint_file, map_location=device, weights_only=True)
-    model.load_state_dict(checkpoint["state_dict"], strict=False)
-    optimizer.load_state_dict(checkpoint["optimizer"])
-    for param_group in optimizer.param_groups:
-        param_group["lr"] = lr
+def save_point_sche(model, optimizer, schedule, filename='my_checkpoint.pth.tar'):
+    torch.save(_bundle(model, optimizer, schedule=schedule.state_dict()), filename)
 
 
 def load_model(checkpoint_file, model, device):
-    checkpoint = torch.load(checkpoint_file, map_location=device, weights_only=True)
-    model.load_state_dict(checkpoint["state_dict"], strict=False)
+    """Weights only (a file this code or the reference wrote; loaded without unpickling arbitrary objects)."""
+    state = torch.load(checkpoint_file, map_location=device, weights_only=True)
+    model.load_state_dict(state['state_dict'], strict=False)
+    return state
+
+
+def load_checkpoint(checkpoint_file, model, optimizer, lr, device):
+    state = load_model(checkpoint_file, model, device)
+    optimizer.load_state_dict(state['optimizer'])
+    for group in optimizer.param_groups:
+        group['lr'] = lr
 
 
 def seed_everything(seed=42):
-    os.environ["PYTHONHASHSEED"] = str(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)
