@@ -220,8 +220,11 @@ def main():
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': K_steps, 'warmup': W_steps,
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: synthetic %dx%d scene, %d-band HSI + %d-band SAR, %dx%d patches, %d logits, '
-                               'batch %d per GPU, fused HIP fwd+CE+bwd+Adam' % (args.size, args.size, C, C2, P, P, args.classes + 1, B),
+        'config': {'workload': '%s: synthetic %dx%d scene, %d-band HSI + %d-band SAR, %dx%d patches, %d logits, '
+                               'batch %d per GPU, fused HIP fwd+CE+bwd+Adam'
+                               % ('configs[1]' if (C, C2, args.size) == (200, 1, 145) else
+                                  ('configs[3] shape' if (C, C2, args.size) == (224, 3, 512) else 'custom'),
+                                  args.size, args.size, C, C2, P, P, args.classes + 1, B),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world,
                    'launch': ('hipGraph x%d steps' % spg) if spg else 'eager',
                    'allreduce': 'none' if world == 1 else ('xgmi one-shot, fused in the reduce+Adam launch' if comm is not None
