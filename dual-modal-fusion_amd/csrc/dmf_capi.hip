@@ -354,6 +354,7 @@ int64_t dmf_attn_workspace_bytes(const dmf_shape* s, int32_t B) {
 
 int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                          void* workspace, float* logits, int32_t* pred, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || workspace == nullptr || logits == nullptr)
     return fail("%s", "null argument");
   if (!s->attention) return fail("%s", "dmf_forward_attn needs shape->attention == 1");
@@ -390,6 +391,7 @@ int64_t dmf_attn_train_workspace_bytes(const dmf_shape* s, int32_t B) {
 int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                                const int32_t* labels, const float* dlogits, float loss_scale, float* logits, float* loss,
                                void* workspace, void* attn_workspace, int32_t* adam_step_dev, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || workspace == nullptr ||
       attn_workspace == nullptr || logits == nullptr)
     return fail("%s", "null argument");
@@ -433,6 +435,7 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
 
 int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                     float* logits, int32_t* pred, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;          // an empty batch is a no-op (its tensors have null data pointers)
   if (logits == nullptr) return fail("%s", "null logits");
   if (s != nullptr && s->attention) return fail("%s", "attention network: use dmf_forward_attn");
   return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, nullptr, stream);
@@ -441,12 +444,14 @@ int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta,
 int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                           const int32_t* labels, float loss_scale, float* logits, float* loss, void* workspace,
                           int32_t* adam_step_dev, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
   if (labels == nullptr || logits == nullptr || loss == nullptr) return fail("%s", "null labels/logits/loss");
   return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, adam_step_dev, stream);
 }
 
 int32_t dmf_backward_dlogits(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                              const float* dlogits, void* workspace, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
   if (dlogits == nullptr) return fail("%s", "null dlogits");
   return run_patch(s, in, MODE_BWD, theta, pool_w, nullptr, dlogits, 1.f, nullptr, nullptr, nullptr, workspace, nullptr, stream);
 }

@@ -269,6 +269,61 @@ def test_unsupported_shape_fails_loudly():
         Net(make_cfg('tiny'))(torch.zeros(1, 8, 5, 5), torch.zeros(1, 1, 20, 20))
 
 
+def test_edge_cases_at_the_c_abi():
+    """Empty batches are no-ops, malformed requests fail with a message (never a fault on the GPU): wrong tensor
+    shapes, coordinates outside the padded scene, labels out of range, K above DMF_KMAX, attention nets sent to the
+    conv-only entry points, plan lengths that are not whole batches."""
+    from dmf import lib
+    from dmf.engine import Scene, TrainEngine, EvalEngine
+    cfg, ref, hip = nets('tiny1')
+    C, C2, P, S, K = SHAPES['tiny1']
+    theta = hip.flat_parameters()
+    # B = 0: forward and the train step return without launching
+    a0, b0 = torch.zeros(0, C, P, P, device='cuda'), torch.zeros(0, C2, P, P, device='cuda')
+    lib.forward(hip.shape, lib.input_patches(hip.shape, a0, b0), theta, hip.pool_w, torch.empty(0, K, device='cuda'))
+    assert hip(a0, b0).shape == (0, K)
+    # wrong patch shape
+    with pytest.raises(lib.DmfError, match='do not match'):
+        lib.input_patches(hip.shape, torch.zeros(2, C, P + 1, P, device='cuda'), torch.zeros(2, C2, P, P, device='cuda'))
+    # coordinates outside the scene are refused on the host
+    A, Bm = _scene('tiny1', 9, 9)
+    scene = Scene(A.numpy(), Bm.numpy(), 'cuda:0')
+    ev = EvalEngine(hip, scene, 8)
+    with pytest.raises(lib.DmfError, match='outside the padded scene'):
+        ev.confusion(np.array([[9, 0]], dtype=np.int32), np.array([1], dtype=np.int32))
+    with pytest.raises(lib.DmfError, match='outside the padded scene'):
+        ev.label_map(np.array([[0, -1]], dtype=np.int32), 9, 9)
+    eng = TrainEngine(hip, scene, 4, lr=1e-3)
+    with pytest.raises(lib.DmfError, match='multiple of the batch size'):
+        eng.load_plan(np.zeros((6, 2), dtype=np.int32), np.ones(6, dtype=np.int32))
+    with pytest.raises(lib.DmfError, match='label outside'):
+        eng.load_plan(np.zeros((4, 2), dtype=np.int32), np.full(4, K, dtype=np.int32))
+    with pytest.raises(lib.DmfError, match='at most'):
+        eng.step(torch.zeros(5, 2, dtype=torch.int32, device='cuda'), torch.ones(5, dtype=torch.int32, device='cuda'))
+    # K above DMF_KMAX
+    big = lib.make_shape(dict(hip.arch, K=65))
+    with pytest.raises(lib.DmfError):
+        lib.shape_supported(big)
+    # attention nets must use their own entry points
+    cfg_a, ref_a, hip_a = _attn_nets('tiny1')
+    a, b, t = rand_batch('tiny1', 3)
+    inp = lib.input_patches(hip_a.shape, a.cuda(), b.cuda())
+    with pytest.raises(lib.DmfError, match='attention'):
+        lib.forward(hip_a.shape, inp, hip_a.flat_parameters(), hip_a.pool_w, torch.empty(3, K, device='cuda'))
+    ws = torch.empty(lib.workspace_bytes(hip_a.shape, 3) // 4, device='cuda')
+    with pytest.raises(lib.DmfError, match='attention'):
+        lib.train_fwd_bwd(hip_a.shape, inp, hip_a.flat_parameters(), hip_a.pool_w, t.int().cuda(), 1.0, torch.empty(3, K, device='cuda'),
+                          torch.empty(3, device='cuda'), ws)
+    aws = torch.empty(lib.attn_train_workspace_bytes(hip_a.shape, 3), dtype=torch.uint8, device='cuda')
+    with pytest.raises(lib.DmfError, match='exactly one'):
+        lib.train_attn_fwd_bwd(hip_a.shape, inp, hip_a.flat_parameters(), hip_a.pool_w, None, None, 1.0,
+                               torch.empty(3, K, device='cuda'), None, ws, aws)
+    # qua_loss: logits must be [4*bs, K]
+    with pytest.raises(lib.DmfError, match='4\\*bs'):
+        lib.qua_loss(torch.zeros(7, K, device='cuda'), 2, torch.zeros(2, dtype=torch.int32, device='cuda'),
+                     lib.QuaParams(alpha=0.1, beta=0.05, gamma=1.0, epsilon=1e-8, tao=0.1))
+
+
 # ------------------------------------------------------------------------------------------------ attention (forward)
 def _attn_nets(name, seed=0):
     from oracle.gmfnet_ref import Net as RefNet
