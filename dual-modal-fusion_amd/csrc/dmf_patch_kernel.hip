@@ -535,6 +535,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   if (tid0 < KMAX) preB = tid0 < K ? th[(unsigned)(Sh::oFc2w + K * Sh::H + tid0)] : 0.f;
   if ((MODE == MODE_TRAIN || MODE == MODE_DENSE) && a.adam_step != nullptr && blockIdx.x == 0 && tid0 == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? a.in.cursor[0] * B : 0;   // epoch-plan offset of this batch
+  STAMP(13);
   const bool pre_issued = AUX_WAVE && a.in.mode == 1 && (int)blockIdx.x < B;
   int label0 = 0;                             // (fetched before the gather: a younger load could only be waited for
   if (MODE == MODE_TRAIN && pre_issued) label0 = a.labels[boff + blockIdx.x];   //  together with the whole window)
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     aux_gather_dma<Sh>(a.in, boff + blockIdx.x, sAux, lane);
     x_gather_dma<Sh>(a.in, boff + blockIdx.x, sX, wave, lane);
   }
+  STAMP(14);
 #pragma unroll
   for (int q = 0; q < NPRE_P; ++q) { const int i = tid0 + q * Sh::NT; if (i < Sh::P * L::RS) sPool[i] = preP[q]; }
 #pragma unroll

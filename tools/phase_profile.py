@@ -58,6 +58,7 @@ def main():
     full = stamps.cpu().numpy().reshape(nblk, 16).astype(np.float64)
     print('  %-34s %9.0f' % ('prologue (kernel entry -> tables in LDS)', np.median(full[:, 12] - full[:, 11])))
     print('  %-34s %9.0f' % ('kernel entry -> end of patch', np.median(full[:, 10] - full[:, 11])))
+    print('  %-34s %9.0f %9.0f %9.0f' % ('entry -> table loads issued + cursor read | -> gather issued | -> tables in LDS', np.median(full[:, 13] - full[:, 11]), np.median(full[:, 14] - full[:, 13]), np.median(full[:, 12] - full[:, 14])))
     span = (s[:, 10].max() - s[:, 0].min())
     print('first start -> last end across workgroups: %.0f ticks' % span)
 

@@ -1,0 +1,98 @@
+// micro-benchmark: cost of a hand-rolled device-wide barrier (256 workgroups x 640 threads, 1 per CU) on gfx950
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
+template <int VAR>
+__device__ __forceinline__ void grid_barrier_v(unsigned* ctr, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (VAR == 0) {          // release add, acquire spin (as above)
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    } else if (VAR == 1) {   // relaxed add + relaxed spin, fences outside the loop
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {                 // no fences at all (pure synchronisation cost)
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+template <int VAR, bool FENCE>
+__global__ __launch_bounds__(640) void bar_kernel_v(unsigned* ctr, int iters, unsigned long long* out, float* buf) {
+  extern __shared__ float lds[];
+  lds[threadIdx.x] = 1.f;
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    buf[blockIdx.x * 640 + threadIdx.x] += 1.f;
+    if (FENCE) __threadfence();
+    grid_barrier_v<VAR>(ctr, (unsigned)(i + 1) * gridDim.x);
+    lds[threadIdx.x] += buf[((blockIdx.x + 1) % gridDim.x) * 640 + threadIdx.x];
+  }
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (lds[threadIdx.x] < 0) buf[0] = lds[threadIdx.x];
+}
+
+__global__ __launch_bounds__(640) void bar_kernel(unsigned* ctr, int iters, unsigned long long* out, float* buf) {
+  extern __shared__ float lds[];
+  lds[threadIdx.x] = 1.f;
+  const unsigned long long t0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    buf[blockIdx.x * 640 + threadIdx.x] += 1.f;                   // something to release
+    __threadfence();
+    grid_barrier(ctr, (unsigned)(i + 1) * gridDim.x);
+    // read a neighbour's value to make sure visibility is real
+    lds[threadIdx.x] += buf[((blockIdx.x + 1) % gridDim.x) * 640 + threadIdx.x];
+  }
+  const unsigned long long t1 = wall_clock64();
+  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (lds[threadIdx.x] < 0) buf[0] = lds[threadIdx.x];
+}
+
+int main() {
+  unsigned* ctr; unsigned long long* out; float* buf;
+  const int grid = 256, iters = 200;
+  hipMalloc(&ctr, 4); hipMemset(ctr, 0, 4);
+  hipMalloc(&out, grid * 8); hipMalloc(&buf, grid * 640 * 4); hipMemset(buf, 0, grid * 640 * 4);
+  hipFuncSetAttribute((const void*)bar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  void* args[] = {&ctr, (void*)&iters, &out, &buf};
+  hipError_t e = hipLaunchCooperativeKernel((const void*)bar_kernel, dim3(grid), dim3(640), args, 150 * 1024, 0);
+  printf("launch: %s\n", hipGetErrorString(e));
+  e = hipDeviceSynchronize();
+  printf("sync: %s\n", hipGetErrorString(e));
+  unsigned long long h[256];
+  hipMemcpy(h, out, grid * 8, hipMemcpyDeviceToHost);
+  unsigned long long mx = 0; for (int i = 0; i < grid; ++i) mx = h[i] > mx ? h[i] : mx;
+  printf("grid barrier: %.3f us per iteration (wall clock 100 MHz ticks: %llu for %d iters)\n", mx / 100.0 / iters, mx, iters);
+  auto run = [&](const void* fn, const char* name) {
+    hipMemset(ctr, 0, 4);
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipError_t e2 = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(640), args, 150 * 1024, 0);
+    hipError_t e3 = hipDeviceSynchronize();
+    hipMemcpy(h, out, grid * 8, hipMemcpyDeviceToHost);
+    unsigned long long m2 = 0; for (int i = 0; i < grid; ++i) m2 = h[i] > m2 ? h[i] : m2;
+    printf("%-40s %s/%s  %.3f us per iteration\n", name, hipGetErrorString(e2), hipGetErrorString(e3), m2 / 100.0 / iters);
+  };
+  run((const void*)bar_kernel_v<0, true>, "release/acquire atomics + threadfence");
+  run((const void*)bar_kernel_v<0, false>, "release/acquire atomics");
+  run((const void*)bar_kernel_v<1, false>, "relaxed atomics, fences outside loop");
+  run((const void*)bar_kernel_v<2, false>, "relaxed atomics, no fences");
+  float hb[640]; hipMemcpy(hb, buf, 640 * 4, hipMemcpyDeviceToHost);
+  printf("buf[0]=%f (expect %d)\n", hb[0], iters);
+  return 0;
+}
