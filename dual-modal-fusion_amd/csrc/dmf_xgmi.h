@@ -5,8 +5,8 @@
 //   flags : [region 2][src rank world][nblk] int32, then one status word
 // Protocol for block `blk` at sequence number `seq` (monotonic, identical on all ranks) — a PUSH exchange:
 //   1. write own values into data[r][region][seq&1][rank] of EVERY rank r      (system-scope stores through the IPC mapping)
-//   2. flags[peer][region][rank][blk] = seq on every peer                      (release, system scope)
-//   3. wait until flags[rank][region][peer][blk] >= seq for every peer         (acquire, bounded by a wall-clock timeout)
+//   2. one system-scope release per block, then flags[peer][region][rank][blk] = seq on every peer
+//   3. wait until flags[rank][region][peer][blk] >= seq for every peer         (relaxed polls, bounded by a wall-clock timeout)
 //   4. read the world values from the OWN inbox and add them in rank order
 // Reads only ever go to memory the reader allocated itself as uncached, so they can never be served from a stale cache
 // line: an IPC import does not carry the exporter's uncached attribute (a pull over the imported mapping was seen to
@@ -45,17 +45,28 @@ __device__ __forceinline__ float xgmi_exchange(const XgmiDev& x, int region, int
       if (r < x.world)
         __hip_atomic_store(x.data[r] + base + (int64_t)x.rank * x.cap + idx, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __threadfence_system();
+  // Cache maintenance is the expensive part of any cross-agent handshake on this part (a device-scope release /
+  // acquire pair costs ~10 us when every thread does it, tools/gridbar.hip), so it is done ONCE per block: the value
+  // stores above are write-through system-scope stores; the barrier below waits until every thread's stores have been
+  // acknowledged; thread 0 then issues one system-scope release and raises the flags with plain system-scope stores.
+  // Waiting polls with relaxed loads; the values are read from the reader's own UNCACHED inbox, so no acquire
+  // invalidation is needed on this side.
   __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#pragma unroll 1
+    for (int r = 0; r < x.world; ++r)
+      if (r != x.rank)
+        __hip_atomic_store(x.flags[r] + ((int64_t)(region * x.world + x.rank)) * x.nblk + blk, seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (tid < x.world && tid != x.rank) {
-    __hip_atomic_store(x.flags[tid] + ((int64_t)(region * x.world + x.rank)) * x.nblk + blk, seq, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
     int32_t* mine = x.flags[x.rank] + ((int64_t)(region * x.world + tid)) * x.nblk + blk;
     int32_t* status = x.flags[x.rank] + xgmi_status_index(x.world, x.nblk);
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
       const uint64_t t0 = wall_clock64();
-      while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-        __builtin_amdgcn_s_sleep(8);
+      while (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(4);
         if ((int64_t)(wall_clock64() - t0) > x.timeout_ticks) {
           __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
