@@ -49,7 +49,7 @@ struct AttnTrainArgs {   // must match dmf_capi.hip
   float loss_scale;
   float* logits; float* loss;           // [B][K], [B] (loss may be null)
   float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;   // head vectors for the gradient reduce
-  float* dYa; float* dYb;               // [B][F][P2]
+  float* dYa; float* dYb;               // [B][F][P][RS], RS = P rounded up to 4 (rows 16-byte aligned)
   float* aslab;                         // [gridDim][4*E*F] attention weight gradients (Wq, Wk, Wv, Wo)
   int32_t* pred;                        // forward-only launch: argmax per patch (may be null)
   const bfs* wprep;                     // [NH][WPREP] bf16 weights of every head, already in the LDS layout (attn_prep_kernel)
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
   constexpr int T = L::T, FP = L::FP, DH = L::DH, FO = L::FO, NT = 512;
   constexpr int VS = L::VS, QS = L::QS, KS = L::KS, WS = L::WS, OS = L::OS;
   constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, P2 = Sh::P2;
+  constexpr int RSD = (Sh::P + 3) & ~3;               // row stride of the dense gradient maps (16-byte aligned rows)
   static_assert(E == NH * DH && F == 40 && F2 == 80 && H == 64 && P2 <= T, "attention geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   // every LDS array is a constant offset from the dynamic-LDS symbol: no pointer variables that could be spilled as
@@ -788,8 +789,9 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         for (int r = 0; r < 4; ++r) {
           const int f = 16 * n + 4 * g + r;
           if (f < F) {
-            a.dYa[((size_t)b * F + f) * P2 + tq] = accTa[n][r] + wq * sDz[f];
-            a.dYb[((size_t)b * F + f) * P2 + tq] = accTb[n][r] + wq * sDz[F + f];
+            const size_t o = ((size_t)b * F + f) * (Sh::P * RSD) + (tq / Sh::P) * RSD + (tq % Sh::P);   // [B][F][P][RSD]
+            a.dYa[o] = accTa[n][r] + wq * sDz[f];
+            a.dYb[o] = accTb[n][r] + wq * sDz[F + f];
           }
         }
     }

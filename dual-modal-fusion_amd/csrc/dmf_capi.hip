@@ -384,8 +384,8 @@ int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* t
 
 int64_t dmf_attn_train_workspace_bytes(const dmf_shape* s, int32_t B) {
   if (s == nullptr || B < 0) return -1;
-  // two bf16 token maps + pooled z + the two dense gradient maps [B][F][P*P] + the bf16 weight copies of every head
-  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4 + 2 * (int64_t)s->F * s->P * s->P * 4) + (int64_t)attn_prep_bytes();
+  // two bf16 token maps + pooled z + the two dense gradient maps [B][F][P][RS] + the bf16 weight copies of every head
+  return (int64_t)B * (2 * 128 * 64 * 2 + 2 * s->F * 4 + 2 * (int64_t)s->F * s->P * ((s->P + 3) & ~3) * 4) + (int64_t)attn_prep_bytes();
 }
 
 int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
@@ -408,8 +408,9 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
   unsigned short* tokB = tokA + B * 128 * 64;
   float* z = reinterpret_cast<float*>(tokB + B * 128 * 64);
   float* dYa = z + B * 2 * s->F;
-  float* dYb = dYa + B * s->F * s->P * s->P;
-  unsigned short* wprep = reinterpret_cast<unsigned short*>(dYb + B * s->F * s->P * s->P);
+  const size_t map = (size_t)s->F * s->P * ((s->P + 3) & ~3);       // one patch's dense gradient map, rows padded to 16 B
+  float* dYb = dYa + B * map;
+  unsigned short* wprep = reinterpret_cast<unsigned short*>(dYb + B * map);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (check(attn_prep_launch(theta, L.off[12], L.off[13], L.off[14], L.off[15], wprep, st), "attention weight prep launch")) return 1;
   KArgs a{};

@@ -74,8 +74,8 @@ struct KArgs {
   unsigned short* tokA; // MODE_TOKENS: bf16 token maps [B][128][64] (tokens x channels, zero padded) of both branches
   unsigned short* tokB;
   float* zout;          // MODE_TOKENS: pooled features [B][2F] before attention
-  const float* dYa;     // MODE_DENSE: dL/d(spat_a output) [B][F][P2]
-  const float* dYb;     // MODE_DENSE: dL/d(spat_b output) [B][F][P2]
+  const float* dYa;     // MODE_DENSE: dL/d(spat_a output) [B][F][P][RS] (rows padded to 16 bytes)
+  const float* dYb;     // MODE_DENSE: dL/d(spat_b output) [B][F][P][RS]
   int32_t K;
 };
 
@@ -391,9 +391,17 @@ __device__ __forceinline__ void row_bwd_w(const float* sY, const float pw[Lds<Sh
 #pragma unroll
   for (int k = 0; k < 9; ++k) dw[k] = 0.f;
   db = 0.f;
+  float ddr[L::RS];
+  if (DENSE) {
+#pragma unroll
+    for (int k = 0; k < L::RS / 4; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(dd + r * L::RS + 4 * k);
+      ddr[4 * k] = v.x; ddr[4 * k + 1] = v.y; ddr[4 * k + 2] = v.z; ddr[4 * k + 3] = v.w;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < Sh::P; ++c) {
-    const float d2 = keep_if_bit(DENSE ? dd[r * Sh::P + c] : dz * pw[c], mr, c);
+    const float d2 = keep_if_bit(DENSE ? ddr[c] : dz * pw[c], mr, c);
     db += d2;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -420,10 +428,17 @@ __device__ __forceinline__ void row_bwd_x(float* sY, const float* sPool, const u
     const bool in = rr >= 0 && rr < Sh::P;
     const uint32_t mm = in ? sMk[f * L::MS + rr] : 0u;
     float pw[L::RS];
-    load_row<Sh>(sPool + (in ? rr : r) * L::RS, pw);
+    if (DENSE) {
 #pragma unroll
-    for (int c = 0; c < Sh::P; ++c)
-      g[u][c] = keep_if_bit(DENSE ? dd[(in ? rr : r) * Sh::P + c] : dz * pw[c], mm, c);
+      for (int k = 0; k < L::RS / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(dd + (in ? rr : r) * L::RS + 4 * k);
+        pw[4 * k] = v.x; pw[4 * k + 1] = v.y; pw[4 * k + 2] = v.z; pw[4 * k + 3] = v.w;
+      }
+    } else {
+      load_row<Sh>(sPool + (in ? rr : r) * L::RS, pw);
+    }
+#pragma unroll
+    for (int c = 0; c < Sh::P; ++c) g[u][c] = keep_if_bit(DENSE ? pw[c] : dz * pw[c], mm, c);
   }
   float y1[L::RS];
   float* row = sY + f * L::FSZ + r * L::RS;
@@ -836,8 +851,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     fS = tid >> 4; rS = tid & 15;
     float dza = 0.f, dzb = 0.f;
     constexpr bool DN = (MODE == MODE_DENSE);
-    const float* dda = DN ? a.dYa + ((size_t)b * Sh::F + fSc) * Sh::P2 : nullptr;
-    const float* ddb = DN ? a.dYb + ((size_t)b * Sh::F + fSc) * Sh::P2 : nullptr;
+    const float* dda = DN ? a.dYa + ((size_t)b * Sh::F + fSc) * (Sh::P * L::RS) : nullptr;
+    const float* ddb = DN ? a.dYb + ((size_t)b * Sh::F + fSc) * (Sh::P * L::RS) : nullptr;
     if (!DN && spat) {   // dz[f] = ordered sum of the head waves' partials
 #pragma unroll
       for (int w = 0; w < L::NWH; ++w) { dza += sTmp[w * TMPW + fS]; dzb += sTmp[w * TMPW + Sh::F + fS]; }
