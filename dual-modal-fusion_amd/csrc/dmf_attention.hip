@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #define sOb AT_F(L::fOb)
 #define sObw AT_F(L::fObw)
 #define sDzw AT_F(L::fDzw)
-#define sSt AT_F(L::fSt)   /* per query t: {row max, w_t / row sum, abar_t, -} */
+#define sSt AT_F(L::fSt)   /* per query t: {row max, 1 / row sum, abar_t, w_t} */
 #define sA AT_F(L::fA)
 #define sCw AT_F(L::fCw)
 #define sC AT_F(L::fC)
@@ -582,21 +582,14 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       ASTAMP();
       __syncthreads();                               // a_j visible
       {
-        // abar_t = sum_j P[t][j] a_j ;  c_j (this wave's part) = sum_{t own} bf16(P)[t][j] w_t
+        // abar_t = sum_j P[t][j] a_j      (c = bf16(P)^T w is formed with the own-KEY orientation below: no lane reductions)
         float ab = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) ab = fmaf(s[i][r], sA[16 * i + 4 * g + r], ab);
         ab = xrow_sum(ab);
-        if (g == 0) *reinterpret_cast<float4*>(sSt + 4 * tq) = make_float4(mxq, wq * invq, ab, 0.f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float c = row16_sum(wq * bf2f((__bf16)s[i][r]));
-            if (col == 0) sCw[wave * T + 16 * i + 4 * g + r] = c;
-          }
+        if (g == 0) *reinterpret_cast<float4*>(sSt + 4 * tq) = make_float4(mxq, invq, ab, wq);
         // dS^T in place: s[i][r] = w_t P (a_j - abar_t)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -659,12 +652,6 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         }
       }
 #endif
-      if (tid < T) {
-        float c = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) c += sCw[w * T + tid];
-        sC[tid] = c;
-      }
       if (wave < 6) {                                // dWq_h tile: [d = 16 wmt ..][f = 16 wnt ..] over all 128 tokens
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -689,13 +676,18 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag<QS>(sQ, 16 * i, 0, lane), fk, (f32x4{0.f, 0.f, 0.f, 0.f}));
         const float aj = sA[tq];
         const bool keyok = tq < P2;
+        float cpart = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float4 st = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r));
-            s[i][r] = keyok ? fexp(s[i][r] - st.x) * st.y * (aj - st.z) : 0.f;      // w_t P[t][j] (a_j - abar_t)
+            const float p = fexp(s[i][r] - st.x) * st.y;                             // P[t][j]
+            cpart = fmaf(bf2f((__bf16)p), st.w, cpart);                              // c_j += bf16(P)[t][j] w_t
+            s[i][r] = keyok ? st.w * p * (aj - st.z) : 0.f;                          // w_t P[t][j] (a_j - abar_t)
           }
+        cpart = xrow_sum(cpart);                      // all 128 queries of this key: 32 in the lane, x 4 lane groups
+        if (g == 0) sC[tq] = keyok ? cpart : 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           bf16x8 hi, lo;
