@@ -18,8 +18,8 @@ from function.function import data_padding, data_padding_aux
 from model.gmfnet import Net
 
 P1 = ['stage weights', 'projections', 'S^T + softmax', 'P V, O Wo, obar']
-P2 = ['stage weights', 'projections', 'a_j, g, S^T + softmax', 'abar, c, dS, dQs, dTa, store dq', '(barrier 1)',
-      'c sum, dWq, S own keys, dK, dTb', 'store dK, bbar, c x g', 'dWk, dWv']
+P2 = ['stage weights (+ wait for the previous head)', 'projections', 'a_j, g, S^T + softmax', 'abar, dS, dQs, dTa, store dq', '(barrier 1)',
+      'dWq, S own keys, c, dK, dTb', '(barrier 2) store dK, bbar, c x g', '(barrier 3) dWk, dWv']
 
 
 def main():
