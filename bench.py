@@ -199,6 +199,11 @@ def main():
         torch.cuda.synchronize()
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[n_inst // 10:]]))
 
+    # ---- kappa of the trained net on the held-out split: on-device confusion matrix; with N ranks every rank
+    # classifies its shard of the pixels and the K x K matrices are all-reduced
+    n_test = min(len(test), 8192)
+    ev_eng = EvalEngine(net, scene, 2048)
+    m_test = ev_eng.confusion(xy_tab[test[:n_test]], lab_tab[test[:n_test]], process_group=pg).cpu().numpy().astype(np.float64)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -240,10 +245,7 @@ def main():
 
     # ---- kappa of the trained net on the held-out split (on-device confusion matrix)
     from indicators.kappa import aa_oa_quiet
-    ev_eng = EvalEngine(net, scene, 2048)
-    n_test = min(len(test), 8192)
-    m = ev_eng.confusion(xy_tab[test[:n_test]], lab_tab[test[:n_test]]).cpu().numpy().astype(np.float64)
-    aa, oa, kp = aa_oa_quiet(m)
+    aa, oa, kp = aa_oa_quiet(m_test)
     out['kappa'] = {'gpu': kp, 'oa': oa, 'aa': aa, 'test_patches': int(n_test), 'train_steps': total}
 
     # ---- CPU baseline: oracle restatement of the reference loop on the same first steps (N == 1 only)

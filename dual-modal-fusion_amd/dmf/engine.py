@@ -209,12 +209,18 @@ class EvalEngine:
             lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits, self.pred)
         return self.logits[:n], self.pred[:n]
 
-    def confusion(self, xy_all, labels_all, matrix=None):
-        """Confusion matrix [K,K] int64 (rows = prediction) over all given pixels; one D2H at the end."""
+    def confusion(self, xy_all, labels_all, matrix=None, process_group=None):
+        """Confusion matrix [K,K] int64 (rows = prediction) over all given pixels; one D2H at the end.
+        With a process group every rank classifies its contiguous shard of the pixels and the matrices are summed."""
         dev = self.scene.device
         K = self.net.arch['K']
         xy_all = torch.as_tensor(xy_all).to(device=dev, dtype=torch.int32).contiguous()
         labels_all = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
+        if process_group is not None:
+            import torch.distributed as dist
+            from .parallel import shard_range
+            lo, hi = shard_range(xy_all.shape[0], dist.get_rank(process_group), dist.get_world_size(process_group))
+            xy_all, labels_all = xy_all[lo:hi].contiguous(), labels_all[lo:hi].contiguous()
         lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_all.cpu().numpy())
         if matrix is None:
             matrix = torch.zeros(K, K, dtype=torch.int64, device=dev)
@@ -222,11 +228,24 @@ class EvalEngine:
             xy = xy_all[i:i + self.B]
             _, pred = self.predict(xy)
             lib.confusion_accum(pred, labels_all[i:i + self.B], K, matrix)
+        if process_group is not None:
+            from .parallel import allreduce_sum_
+            if dist.get_backend(process_group) == 'nccl':
+                allreduce_sum_(matrix, process_group)
+            else:                                   # gloo (CPU tests, one-GPU rehearsal): reduce on the host
+                matrix.copy_(allreduce_sum_(matrix.cpu(), process_group))
         return matrix
 
-    def label_map(self, xy_all, H, W, label_map=None):
+    def label_map(self, xy_all, H, W, label_map=None, process_group=None):
+        """Predicted class of every given pixel written at (x, y) of an [H, W] int32 map (mainsolver.py:171-183).
+        With a process group the pixels are sharded and the tiles merged (every pixel is written by one rank)."""
         dev = self.scene.device
         xy_all = torch.as_tensor(xy_all).to(device=dev, dtype=torch.int32).contiguous()
+        if process_group is not None:
+            import torch.distributed as dist
+            from .parallel import shard_range
+            lo, hi = shard_range(xy_all.shape[0], dist.get_rank(process_group), dist.get_world_size(process_group))
+            xy_all = xy_all[lo:hi].contiguous()
         lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_all.cpu().numpy())
         if label_map is None:
             label_map = torch.zeros(H, W, dtype=torch.int32, device=dev)
@@ -234,6 +253,12 @@ class EvalEngine:
             xy = xy_all[i:i + self.B]
             _, pred = self.predict(xy)
             lib.labelmap_write(pred, xy, W, label_map)
+        if process_group is not None:
+            from .parallel import allreduce_max_
+            if dist.get_backend(process_group) == 'nccl':
+                allreduce_max_(label_map, process_group)
+            else:
+                label_map.copy_(allreduce_max_(label_map.cpu(), process_group))
         return label_map
 
 

@@ -185,3 +185,34 @@ def test_two_rank_dp_equals_single_rank_global_batch():
     err = np.abs(two - one).max()
     print('2-rank vs 1-rank parameters after %d steps: max abs diff %.2e' % (STEPS, err))
     assert err < 2e-5
+
+
+def _eval_sharded(rank, world, port, q):
+    import torch.distributed as dist
+    MS, PAN, xy, lab = _problem(301)                       # 301 pixels: shards of 151 and 150
+    from dmf.engine import EvalEngine, Scene
+    from model.gmfnet import Net
+    pg = None
+    if world > 1:
+        import datetime
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        pg = dist.group.WORLD
+    torch.manual_seed(0)
+    net = Net(CFG).to('cuda:0')
+    ev = EvalEngine(net, Scene(MS, PAN, 'cuda:0'), 64)
+    m = ev.confusion(xy, lab, process_group=pg).cpu().numpy()
+    lm = ev.label_map(xy, 20, 20, process_group=pg).cpu().numpy()
+    if rank == 0:
+        q.put((m, lm))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluation_equals_single_rank():
+    """Evaluation / colouring over a process group: every rank classifies its shard of the pixels, the
+    K x K confusion matrix is all-reduced (sum), label-map tiles are merged — identical to one rank doing all of it."""
+    m2, lm2 = _run_ranks(_eval_sharded, 2, ())
+    m1, lm1 = _run_ranks(_eval_sharded, 1, ())
+    assert m1.sum() == 301 and np.array_equal(m1, m2) and np.array_equal(lm1, lm2)

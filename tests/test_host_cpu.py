@@ -302,3 +302,17 @@ def test_read_tif_and_label_mat(golden_dir):
         assert np.array_equal(label_mat2np(cfg), lab) and np.array_equal(np.load(tmp + 'label.npy'), lab)
     finally:
         shutil.rmtree(tmp)
+
+
+def test_shard_ranges_cover_everything_once():
+    from dmf.parallel import shard_batch, shard_range
+    for n in (0, 1, 7, 301, 1024):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_batch(512, 3, 8) == (192, 256)
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)
