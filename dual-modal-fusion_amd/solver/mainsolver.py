@@ -11,6 +11,10 @@ Two execution paths, same arithmetic:
     materialisation, no per-step host sync, confusion matrix and label maps built on the device;
   * drop-in (`fast_path: 0`): the reference's own loop body (mainsolver.py:49-55) over materialised batches through
     `Net.forward` / autograd / torch ADAM.
+Data parallel (`test.py` under `torch.distributed.run`, fast path only): every rank holds the scene, iterates the SAME
+shuffled index stream (same seed) and trains on its contiguous shard of each global batch (a batch that the world size
+does not divide is trimmed to the largest multiple); the gradient exchange is the engine's; validation runs on every
+rank (identical decisions), test / colour shard the pixels (dmf/parallel.py); rank 0 writes the artefacts.
 Deliberate differences: `test()` evaluates the whole test split when `test.full: 1` (the reference always stops
 after the first batch, :142 — that stays the default); the t-SNE plot inside `test()` and the visualisation
 helpers (:110-136,211-441) are out of scope; `nohup: 1` does not crash (reference bug at :76).
@@ -36,6 +40,9 @@ class Solver(BaseSolver):
         self.test_time = 0
         self.matrix = None
         self.engine = None
+        self.process_group = None                      # set by the launcher for data-parallel runs (test.py)
+        self.comm = None
+        self.rank, self.world = 0, 1
         if self.cfg['train']['pretrained']:
             self.init_model()
 
@@ -90,11 +97,16 @@ class Solver(BaseSolver):
                 val_loss = self._valid_pass(best_loss)
                 if val_loss < best_loss:
                     best_loss, best_epoch = val_loss, self.epoch
-                    torch.save(self.cur_model.state_dict(), self.cfg['RESULT_output'] + str(self.time) + '_weights.pth')
+                    if self.rank == 0:
+                        torch.save(self.cur_model.state_dict(), self.cfg['RESULT_output'] + str(self.time) + '_weights.pth')
                     if self.cfg['nohup']:
                         print("best epoch now is {}".format(self.epoch))
-            opt = self._export_optimizer() if self.fast else self.optimizer
-            save_checkpoint(self.cur_model, opt, self.cfg['RESULT_output'] + str(self.time) + '_curweights.pth')
+            if self.rank == 0:
+                opt = self._export_optimizer() if self.fast else self.optimizer
+                save_checkpoint(self.cur_model, opt, self.cfg['RESULT_output'] + str(self.time) + '_curweights.pth')
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.barrier(self.process_group)               # the files exist before any rank goes on to load them
             if self.cfg['nohup']:
                 print("{} times {}th epoch is trained, loss {:.6f}".format(self.time, self.epoch, last))
             self.epoch += 1
@@ -106,14 +118,23 @@ class Solver(BaseSolver):
         if self.cfg['schedule']['loss'] != 'Criterion':
             raise ValueError('the fused HIP step implements the Criterion (cross-entropy) loss')
         lr, betas, eps = adam_hparams(self.cfg)
-        self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'], lr=lr, betas=betas, eps=eps,
-                                  process_group=getattr(self, 'process_group', None))
+        if self.cfg['batchsize'] % self.world:
+            raise ValueError('batchsize %d is not divisible by the %d ranks' % (self.cfg['batchsize'], self.world))
+        self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'] // self.world, lr=lr, betas=betas, eps=eps,
+                                  process_group=self.process_group, comm=self.comm)
         self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
 
     def _train_epoch_fast(self):
-        eng, B = self.engine, self.cfg['batchsize']
+        eng, B = self.engine, self.cfg['batchsize'] // self.world
         eng.lr = epoch_lr(self.cfg, self.epoch)
         batches = [self._xy_labels(b) for b in self.train_index_loader]      # the epoch's shuffled coordinates
+        if self.world > 1:                                                   # this rank's contiguous shard of every batch
+            cut = []
+            for xy, lab in batches:
+                per = xy.shape[0] // self.world                             # (a remainder is dropped, see the module text)
+                if per:
+                    cut.append((xy[self.rank * per:(self.rank + 1) * per], lab[self.rank * per:(self.rank + 1) * per]))
+            batches = cut
         full = [b for b in batches if b[0].shape[0] == B]
         losses = []
         if full:
@@ -190,7 +211,13 @@ class Solver(BaseSolver):
         K = self.cfg['Categories_Number']
         full = bool(self.cfg['test'].get('full', 0))
         with torch.no_grad():
-            if self.fast:
+            if self.fast and full and self.world > 1:
+                # whole split, sharded: every rank classifies its part of the pixels, the matrices are summed
+                parts = [self._xy_labels(b) for b in self.test_index_loader]
+                matrix = self.eval_engine.confusion(torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
+                                                    process_group=self.process_group)
+                test_matrix = matrix.cpu().numpy().astype(np.float64)
+            elif self.fast:
                 from dmf import lib
                 matrix = torch.zeros(K, K, dtype=torch.int64, device=self.DEVICE)
                 for batch in self.test_index_loader:
@@ -210,7 +237,11 @@ class Solver(BaseSolver):
                         break
         self.test_time = time.time() - time1
         self.test_matrix = test_matrix
-        self.indicator()
+        if self.rank == 0:
+            self.indicator()
+        else:
+            from indicators.kappa import aa_oa_quiet
+            self.result = list(aa_oa_quiet(test_matrix)) + [None]
 
     # ------------------------------------------------------------------ colour
     def color(self):
@@ -225,7 +256,10 @@ class Solver(BaseSolver):
             for use, loaders in ((self.cfg['color']['supervised'], (self.color_index_loader1, self.color_loader1)),
                                  (self.cfg['color']['unsupervised'], (self.color_index_loader2, self.color_loader2))):
                 m = torch.zeros(H, W, dtype=torch.int32, device=self.DEVICE) if self.fast else np.zeros([H, W], dtype=np.int64)
-                if use:
+                if use and self.fast and self.world > 1:
+                    xy_all = torch.cat([self._xy_labels(b)[0] for b in loaders[0]])
+                    m = self.eval_engine.label_map(xy_all, H, W, process_group=self.process_group)
+                elif use:
                     for batch in loaders[0 if self.fast else 1]:
                         if self.fast:
                             from dmf import lib
@@ -240,7 +274,7 @@ class Solver(BaseSolver):
         label_np1 = maps[0]
         label_np2 = np.where(maps[1] != 0, maps[1], maps[0]) if self.cfg['color']['unsupervised'] else maps[0]
         self.label_maps = (label_np1, label_np2)
-        if self.cfg['color']['supervised']:
+        if self.cfg['color']['supervised'] and self.rank == 0:
             Image.fromarray(lut[label_np1]).save(self.cfg['RESULT_output'] + str(self.time) + "_pic_1.png")
             Image.fromarray(lut[label_np2]).save(self.cfg['RESULT_output'] + str(self.time) + "_pic_2.png")
 

@@ -216,3 +216,55 @@ def test_sharded_evaluation_equals_single_rank():
     m2, lm2 = _run_ranks(_eval_sharded, 2, ())
     m1, lm1 = _run_ranks(_eval_sharded, 1, ())
     assert m1.sum() == 301 and np.array_equal(m1, m2) and np.array_equal(lm1, lm2)
+
+
+def _solver_dp(rank, world, port, q, tmp):
+    """`Solver(cfg).run()` on the G9 scene, optionally as one of `world` data-parallel ranks (gloo transport)."""
+    import json
+    import torch.distributed as dist
+    sys.path[:0] = [PKG, REPO]
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'g9_trajectory.npz'), allow_pickle=False)
+    d = os.path.join(tmp, 'scene') + '/'
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        np.save(d + 'ms4.tif.npy', g['primary']); np.save(d + 'pan.tif.npy', g['aux']); np.save(d + 'label.npy', g['label'])
+        os.makedirs(os.path.join(tmp, 'out%d' % world), exist_ok=True)
+    cfg = json.loads(str(g['cfg']))
+    cfg.update(data_address=d, RESULT_output=os.path.join(tmp, 'out%d' % world) + '/', RESULT_excel=os.path.join(tmp, 'r%d.xlsx' % world),
+               nohup=1, device='cuda:0', epoch=6, batchsize=32)
+    cfg['test']['full'] = 1
+    cfg['color']['index'] = 1
+    from solver.mainsolver import Solver
+    if world > 1:
+        import datetime
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+        dist.barrier()
+    torch.manual_seed(3407)
+    s = Solver(cfg)
+    if world > 1:
+        s.process_group, s.rank, s.world = dist.group.WORLD, rank, world
+    s.run()
+    if rank == 0:
+        q.put((s.cur_model.flat_parameters().cpu().numpy(), s.test_matrix, s.label_maps[1]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_solver_data_parallel_equals_single_rank():
+    """The solver itself as 2 data-parallel ranks: same shuffled stream, per-rank shards of every batch (the G9 epoch
+    is 3 x 32 + 18 patches: the short batch is an even 18), exchange through the process group, sharded test and colour
+    passes.  Weights after 6 epochs, the whole-split confusion matrix and the label map must equal the 1-rank run."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='dmf_soldp_')
+    try:
+        two = _run_ranks(_solver_dp, 2, (tmp,))
+        one = _run_ranks(_solver_dp, 1, (tmp,))
+        err = np.abs(two[0] - one[0]).max()
+        print('solver 2-rank vs 1-rank parameters after 6 epochs: max abs diff %.2e' % err)
+        assert err < 1e-5
+        assert np.array_equal(two[1], one[1]) and np.array_equal(two[2], one[2])
+    finally:
+        shutil.rmtree(tmp)
