@@ -368,6 +368,12 @@ __device__ __forceinline__ void row_fwd(const float* sY, const float pw[Lds<Sh>:
   }
 }
 
+// slab rows and head vectors are written once and next read by ANOTHER kernel: streaming (non-temporal) stores keep them
+// from sitting dirty in L2 until the end-of-kernel write-back
+__device__ __forceinline__ void slab_put(float* p, bool first, float v) {
+  __builtin_nontemporal_store(first ? v : *p + v, p);
+}
+
 // x if bit c of the row mask is set, else +0: one signed 1-bit field extract (0 / -1) and one AND instead of the
 // and + compare + select the ?: form compiles to
 __device__ __forceinline__ float keep_if_bit(float x, uint32_t mask, int c) {
@@ -877,11 +883,11 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const int oa = Sh::oA2w + fS * 9 + k, ob = Sh::oB2w + fS * 9 + k;
-          slab[oa] = first ? dwa[k] : slab[oa] + dwa[k];
-          slab[ob] = first ? dwb[k] : slab[ob] + dwb[k];
+          slab_put(slab + (oa), first, dwa[k]);
+          slab_put(slab + (ob), first, dwb[k]);
         }
-        slab[Sh::oA2b + fS] = first ? dba : slab[Sh::oA2b + fS] + dba;
-        slab[Sh::oB2b + fS] = first ? dbb : slab[Sh::oB2b + fS] + dbb;
+        slab_put(slab + (Sh::oA2b + fS), first, dba);
+        slab_put(slab + (Sh::oB2b + fS), first, dbb);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -917,12 +923,12 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
       for (int q = 0; q < Sh::TB; ++q) dwl[q] = sum16(dwl[q]);
       if (spat && rS == 0) {
-        slab[Sh::oA1b + fS] = first ? ga : slab[Sh::oA1b + fS] + ga;
-        slab[Sh::oB1b + fS] = first ? gb : slab[Sh::oB1b + fS] + gb;
+        slab_put(slab + (Sh::oA1b + fS), first, ga);
+        slab_put(slab + (Sh::oB1b + fS), first, gb);
 #pragma unroll
         for (int q = 0; q < Sh::TB; ++q) {
           const int o = Sh::oB1w + fS * Sh::TB + q;
-          slab[o] = first ? dwl[q] : slab[o] + dwl[q];
+          slab_put(slab + (o), first, dwl[q]);
         }
       }
     }
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
             sacc += pbase[(e / L::PW) * L::Cs + (e % L::PW)];
           }
           const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
-          slab[o] = first ? sacc : slab[o] + sacc;
+          slab_put(slab + (o), first, sacc);
         }
       } else {
       float* scr = L::OWN_SLICE ? (sX + g * Sh::Cg) : (sGscr + blk * (NSLW * 4 * Sh::Cg));
@@ -1016,7 +1022,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
         for (int q = 0; q < NSLW; ++q) sacc += scr[(q * 4 + m) * SROW + j];
         const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
-        slab[o] = first ? sacc : slab[o] + sacc;
+        slab_put(slab + (o), first, sacc);
       }
       }   // aligned groups
     }
