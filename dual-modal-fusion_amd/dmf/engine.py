@@ -67,6 +67,7 @@ class TrainEngine:
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.plan_xy = self.plan_labels = self.loss_hist = None
+        self.host_cursor = 0
         self.graph = None
         self.graph_steps = 0
 
@@ -132,6 +133,7 @@ class TrainEngine:
             self.loss_hist = torch.zeros(n, device=dev)
             self.graph = None
         self.dev_cursor.zero_()
+        self.host_cursor = 0
         self.dev_step.fill_(self.step_count)
         self.plan_steps = n
         return n
@@ -139,6 +141,13 @@ class TrainEngine:
     def _plan_step(self):
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=self.B, cursor=self.dev_cursor)
         self._launch(inp, self.plan_labels, self.dev_step, self.dev_cursor, self.loss_hist)
+        self.host_cursor += 1
+
+    def _fill_window(self, n):
+        """Copy the next n steps of the plan into the fixed window the captured graph reads (two small async copies)."""
+        lo, hi = self.host_cursor * self.B, (self.host_cursor + n) * self.B
+        self.win_xy.copy_(self.plan_xy[lo:hi])
+        self.win_lab.copy_(self.plan_labels[lo:hi])
 
     def run_plan(self, steps=None, steps_per_graph=0):
         """Run `steps` steps of the loaded plan (default: all).  steps_per_graph > 0 replays a captured hipGraph
@@ -149,8 +158,10 @@ class TrainEngine:
             if self.graph is None or self.graph_steps != steps_per_graph:
                 self._capture(steps_per_graph)
             while steps - done >= steps_per_graph:
+                self._fill_window(steps_per_graph)
                 self.graph.replay()
                 self.step_count += steps_per_graph
+                self.host_cursor += steps_per_graph
                 done += steps_per_graph
         for _ in range(steps - done):
             self._plan_step()
@@ -169,11 +180,24 @@ class TrainEngine:
         self.step_count = count0
         if self.comm is not None:                  # the eager step used up an exchange sequence number; the bias is
             self.comm.rewind(1)                    # a launch argument, so it has to move BEFORE the capture
+        self.host_cursor -= 1                      # (the eager step above advanced it)
+        # Inside the graph step k reads its coordinates and labels from slot k of a FIXED window (plain pointers baked
+        # into the launch) instead of plan[cursor]: every kernel starts cold after the previous kernel's cache
+        # write-back / invalidate, and `kernarg -> cursor -> coordinates -> gather` is one dependent miss longer than
+        # `kernarg -> coordinates -> gather`.  The window is refilled from the plan before every replay.
+        dev = self.scene.device
+        self.win_xy = torch.empty(n * self.B, 2, dtype=torch.int32, device=dev)
+        self.win_lab = torch.empty(n * self.B, dtype=torch.int32, device=dev)
+        if self.host_cursor + n <= self.plan_steps:
+            self._fill_window(n)
+        else:
+            self.win_xy.zero_(); self.win_lab.zero_()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(n):
-                self._plan_step()
+            for k in range(n):
+                inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.win_xy[k * self.B:(k + 1) * self.B])
+                self._launch(inp, self.win_lab[k * self.B:(k + 1) * self.B], self.dev_step, self.dev_cursor, self.loss_hist)
         self.step_count = count0
         self.graph, self.graph_steps = g, n
 
