@@ -31,31 +31,13 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "../../include/dmf.h"
-#include "dmf_shapes.h"
+#include "dmf_kargs.h"
 
 namespace dmf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bfs;
-
-struct AttnTrainArgs {   // must match dmf_capi.hip
-  const bfs* tokA; const bfs* tokB;     // [B][128][64]
-  const float* zin;                     // [B][2F]
-  const float* theta; const float* pool;
-  const int32_t* labels; const int32_t* cursor;   // labels[(*cursor) * B + b]   (cursor may be null)
-  const float* dlogits;                 // used when labels == null: caller-supplied dL/dlogits [B][K]
-  float loss_scale;
-  float* logits; float* loss;           // [B][K], [B] (loss may be null)
-  float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;   // head vectors for the gradient reduce
-  float* dYa; float* dYb;               // [B][F][P][RS], RS = P rounded up to 4 (rows 16-byte aligned)
-  float* aslab;                         // [gridDim][4*E*F] attention weight gradients (Wq, Wk, Wv, Wo)
-  int32_t* pred;                        // forward-only launch: argmax per patch (may be null)
-  const bfs* wprep;                     // [NH][WPREP] bf16 weights of every head, already in the LDS layout (attn_prep_kernel)
-  int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
-  int32_t B, K;
-};
 
 // Diagnostic build only (-DDMF_STAMPS, tools/attn_phase_profile.py): clock stamps of wave 0 along one patch.
 #ifdef DMF_STAMPS

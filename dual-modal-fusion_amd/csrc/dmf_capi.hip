@@ -5,77 +5,13 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
-#include "../../include/dmf.h"
-#include "dmf_shapes.h"
+#include "dmf_kargs.h"
 #include "dmf_xgmi.h"
 
 namespace dmf {
-
-struct KArgs {   // must match dmf_patch_kernel.hip
-  dmf_input in;
-  const float* theta;
-  const float* pool;
-  const int32_t* labels;
-  const float* dlogits;
-  float loss_scale;
-  float* logits;
-  float* loss;
-  int32_t* pred;
-  float* slab;
-  float* ws_z;
-  float* ws_h;
-  float* ws_dh;
-  float* ws_dl;
-  int32_t* adam_step;
-  unsigned short* tokA;
-  unsigned short* tokB;
-  float* zout;
-  const float* dYa;
-  const float* dYb;
-  int32_t K;
-};
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4 };
-
-struct AttnTrainArgs {   // must match dmf_attention.hip
-  const unsigned short* tokA; const unsigned short* tokB;
-  const float* zin;
-  const float* theta; const float* pool;
-  const int32_t* labels; const int32_t* cursor;
-  const float* dlogits;
-  float loss_scale;
-  float* logits; float* loss;
-  float* ws_z; float* ws_h; float* ws_dh; float* ws_dl;
-  float* dYa; float* dYb;
-  float* aslab;
-  int32_t* pred;
-  const unsigned short* wprep;
-  int64_t oWq, oWk, oWv, oWo, oFc1w, oFc1b, oFc2w, oFc2b;
-  int32_t B, K;
-};
-size_t attn_prep_bytes();
-hipError_t attn_prep_launch(const float* theta, int64_t oWq, int64_t oWk, int64_t oWv, int64_t oWo, void* out, hipStream_t st);
-hipError_t attn_train_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st);
-hipError_t attn_forward_dispatch(const dmf_shape& s, const AttnTrainArgs& a, int grid, hipStream_t st);
-int attn_shape_supported(const dmf_shape& s);
-
-struct QuaArgs {   // must match dmf_qua.hip
-  const float* logits; int bs, K;
-  const int32_t* labels; const int32_t* cursor;
-  float alpha, beta, gamma, eps, tao, grad_scale;
-  float* loss; float* loss_hist; float* dlogits;
-};
-hipError_t launch_qua_loss(const QuaArgs& a, hipStream_t st);
-hipError_t launch_pair_argmax(const float* logits, int bs, int K, int32_t* pred, hipStream_t st);
-hipError_t launch_band_mean(const float* x, int layout, int64_t n_img, int64_t n_pix, int C, float* out, hipStream_t st);
-
-#ifdef DMF_STAMPS
-hipError_t set_attn_stamps(unsigned long long* p);
-hipError_t set_stamps(unsigned long long* p);
-#endif
-int patch_shape_supported(const dmf_shape& s);
-hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -343,6 +279,10 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
     a.ws_dh = ws + w.dh;
     a.ws_dl = ws + w.dl;
   }
+  // the wave-per-channel-block kernel where it is built for the shape; DMF_PATCH_V1=1 forces the generic kernel (A/B runs)
+  static const bool force_v1 = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
+  if (!force_v1 && patch_v2_supported(*s, mode))
+    return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel (v2) launch");
   return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }
 
@@ -663,6 +603,7 @@ int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, doubl
 #ifdef DMF_STAMPS
 int32_t dmf_debug_set_attn_stamps(void* p) { return check(dmf::set_attn_stamps(static_cast<unsigned long long*>(p)), "set_attn_stamps"); }
 int32_t dmf_debug_set_stamps(void* p) { return check(dmf::set_stamps(static_cast<unsigned long long*>(p)), "set_stamps"); }
+int32_t dmf_debug_set_v2_stamps(void* p) { return check(dmf::set_v2_stamps(static_cast<unsigned long long*>(p)), "set_v2_stamps"); }
 #endif
 
 }  // extern "C"

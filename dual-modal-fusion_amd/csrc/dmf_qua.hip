@@ -14,14 +14,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace dmf {
+#include "dmf_kargs.h"
 
-struct QuaArgs {
-  const float* logits; int bs, K;
-  const int32_t* labels; const int32_t* cursor;
-  float alpha, beta, gamma, eps, tao, grad_scale;
-  float* loss; float* loss_hist; float* dlogits;
-};
+namespace dmf {
 
 constexpr int QT = 1024;
 
