@@ -3,26 +3,36 @@
 // Replaces (reference): `output = self.cur_model(data1, data2)`, `loss = self.loss(output, target.long())`,
 // `loss.backward()` — solver/mainsolver.py:52-54 — and the eval forward + argmax (mainsolver.py:109,139,169-170).
 // Arithmetic: oracle/gmfnet_ref.py.  Same inputs, outputs and workspace contract as dmf_patch_kernel.hip (which
-// stays the generic kernel: S > 1, misaligned band groups, token / dense modes).
+// stays the generic kernel: S > 1, misaligned band groups, 16-row patches, token / dense modes).
 //
-// What is different from the first design, and why (round-1 profile: one patch per CU is a latency chain):
-//   * A wavefront owns 4 feature channels of BOTH branches end to end, lanes = 4 channels x 16 patch rows, and
-//     every intermediate (spec_a rows, depthwise rows, masks, gradients) lives in registers: neighbouring patch rows
-//     are neighbouring lanes, fetched by DPP row shifts.  No feature map is ever written to LDS, so the conv pipeline
-//     has no LDS write -> wait -> read hops and no workgroup barrier.
-//   * Each wave gathers ONLY its own band group of the window (Cg bands x P*P pixels, 80-byte runs) by LDS-DMA into a
-//     private slice: no cross-wave dependency on the gather, the wave starts spec_a when ITS bytes have landed.
-//   * The network is piecewise linear and channel f reaches the head only through the pooled scalars z_a[f], z_b[f].
-//     So the whole conv backward is formed with a UNIT upstream gradient right behind the forward (while the rows are
-//     in registers) and scaled by dL/dz[f] at the very end.  The aux branch (forward AND unit backward) therefore runs
-//     under the window gather, and the head (fc1, fc2, softmax-CE, dh, dz) runs on a dedicated wavefront concurrently
-//     with the primary branch's unit backward instead of in front of it.
-//   * The aux rows are loaded global -> registers (never LDS): the compiler orders every LDS access behind ALL
-//     outstanding LDS-DMA (vmcnt(0)), so any LDS read in the aux phase would serialise it behind the window gather.
-//   * Prologue: the per-lane DMA source offsets do not depend on the pixel coordinates, so they are computed while
-//     the coordinates are in flight; coordinates come through the scalar cache.
+// Measured facts this design is built on (tools/valu_rate.hip, tools/phase_profile_v2.py on MI355X):
+//   * A SIMD issues one vector instruction per ~3.2 (v_fmac) to ~4.9 (DPP, packed) cycles however many waves it hosts,
+//     and one wave alone already reaches ~75 % of that.  With one patch per CU the kernel is VECTOR-ISSUE bound: time =
+//     instruction slots of the busiest SIMD x ~4 cycles.  So: few instructions, every lane busy, equal load per SIMD.
+//   * The compiler's waitcnt pass (a) turns every wait into "wait for zero" after a FLAT-encoded LDS-DMA
+//     (global_load_lds), (b) puts every LDS access it can see behind ALL outstanding LDS-DMA.
 //
-// Per patch: barrier 1 = "z complete" (conv waves -> head wave), barrier 2 = "dz complete" (head -> conv waves).
+// Layout: a wavefront owns CPW feature channels of BOTH branches end to end.  A channel takes LPC = P rows + padding
+// lanes (a multiple of 4: 12 for P = 11), channels are packed back to back (5 x 12 = 60 of 64 lanes for the 200-band net:
+// 8 conv waves, two per SIMD, + 1 head wave).  Every intermediate (spec_a rows, depthwise rows, ReLU gates, gradients)
+// lives in registers; the rows above / below are the neighbouring LANES, fetched by whole-wave DPP shifts (wave_shr:1 /
+// wave_shl:1), and a channel's padding lane (Y1 = 0, gate closed) is the zero padding for both of its neighbours.
+// Sums over a channel's rows stop at QUAD level (two quad_perm DPP steps): a 12-lane segment straddles the 16-lane DPP
+// rows, so the NQ quad partials are kept apart (pooled features, slab row copies) and added by whoever consumes them.
+//
+// Flow per patch:
+//   gather   all waves issue the window's 1-KiB LDS-DMA pieces (buffer form; per-lane source offsets from a table built
+//            once); the aux row of a lane was loaded global -> registers just before
+//   aux      lift_b + spat_b forward AND backward for a UNIT upstream gradient, under the gather (tables through LDS
+//            reads the compiler cannot see; see hidden_read)
+//   barrier W  window complete
+//   primary  spec_a (packed FMAs, weights in registers, x from the group's LDS slice), spat_a forward + unit backward
+//   barrier 1  pooled features complete -> the head wave runs fc1 / fc2 / softmax-CE / dh while the conv waves
+//            form the unit spec_a weight gradient from the still-resident window
+//   barrier 2  dh complete -> every quad forms dz of its channel, scales its unit gradients and adds them to its copy of
+//            the workgroup's slab row (LDS); the row leaves in one coalesced pass at the end of the kernel
+// The network is piecewise linear and channel f reaches the head only through the pooled scalars z_a[f], z_b[f]: that is
+// what makes the unit-gradient backward (scaled by dL/dz[f] at the very end) exact.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -36,51 +46,111 @@ namespace dmf {
 // registers (no wait, no store, no branch inside the phases) and lane 0 dumps them right before the wave ends.
 #ifdef DMF_STAMPS
 __device__ unsigned long long* g_v2stamps = nullptr;     // [block][16 waves][16 stamps]
-#define VSTAMP_DECL unsigned long long vst_[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
+#define VSTAMP_DECL unsigned long long vst_[14] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
 #define VSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(vst_[i])); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VSTAMP_W(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_[i])); } while (0)
+#define VSTAMP_RT(i) do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_[i])); } while (0)
 #define VSTAMP_DUMP() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0 && g_v2stamps != nullptr) { \
-    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) g_v2stamps[((size_t)blockIdx.x * 16 + wave) * 16 + i_] = vst_[i_]; } } while (0)
+    _Pragma("unroll") for (int i_ = 0; i_ < 14; ++i_) g_v2stamps[((size_t)blockIdx.x * 16 + wave) * 16 + i_] = vst_[i_]; } } while (0)
 #else
 #define VSTAMP_DECL do { } while (0)
 #define VSTAMP(i) do { } while (0)
+#define VSTAMP_RT(i) do { } while (0)
+#define VSTAMP_W(i) do { } while (0)
 #define VSTAMP_DUMP() do { } while (0)
 #endif
 
 typedef const int32_t __attribute__((address_space(4))) cint;
 
-template <class Sh>
+// LDS-array cycles of one ds_read_b128 x-row read per wave, summed over the conv waves, for a pixel stride CS of the window
+// image [pixel][CS]: the 16 lanes of a service group hold different patch rows, and up to two band groups (a wave's channels
+// straddle groups).  Used to pick the stride's padding at compile time.
+constexpr int v2_read_cost(int CS, int P, int Cg, int lpc, int cpw, int M, int nb) {
+  const int first[4][3] = {{0, 12, 20}, {4, 16, 28}, {32, 44, 52}, {36, 48, 60}};
+  const int count[4][3] = {{4, 4, 8}, {8, 4, 4}, {4, 4, 8}, {8, 4, 4}};
+  int tot = 0;
+  for (int w = 0; w < nb; ++w)
+    for (int sg = 0; sg < 4; ++sg) {
+      int worst = 1;
+      for (int b = 0; b < 64; b += 4) {          // 16-byte reads: bank quads
+        int addrs[16] = {0}, n = 0;
+        for (int part = 0; part < 3; ++part)
+          for (int q = 0; q < count[sg][part]; ++q) {
+            const int l = first[sg][part] + q;
+            const int seg = l / lpc, r = l % lpc;
+            const int f = cpw * w + (seg < cpw ? seg : cpw - 1);
+            const int rc = r < P ? r : P - 1;
+            const int addr = rc * P * CS + (f / M) * Cg;
+            if (addr % 64 == b) {
+              bool seen = false;
+              for (int i = 0; i < n; ++i) seen = seen || addrs[i] == addr;
+              if (!seen) addrs[n++] = addr;
+            }
+          }
+        worst = n > worst ? n : worst;
+      }
+      tot += worst;
+    }
+  return tot;
+}
+// smallest padding (0, 4 or 8 floats) within 30 % of conflict-free; more padding only where the unpadded stride is far off
+constexpr int v2_pick_cs(int C, int P, int Cg, int lpc, int cpw, int M, int nb) {
+  const int ideal = 4 * nb;
+  for (int pad = 0; pad <= 8; pad += 4)
+    if (v2_read_cost(C + pad, P, Cg, lpc, cpw, M, nb) * 10 <= ideal * 13) return C + pad;
+  int best = C, bc = v2_read_cost(C, P, Cg, lpc, cpw, M, nb);
+  for (int pad = 4; pad <= 32; pad += 4) {
+    const int c = v2_read_cost(C + pad, P, Cg, lpc, cpw, M, nb);
+    if (c < bc) { bc = c; best = C + pad; }
+  }
+  return best;
+}
+
+constexpr int v2_pick_cpw(int F, int lpc) {
+  int c = 64 / lpc;
+  while (c > 1 && F % c != 0) --c;
+  return c;
+}
+
+template <class Sh, bool TR = true>
 struct V2 {
-  static constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H;
-  static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Sh::M % 4 == 0 && Cg % 4 == 0 && P <= 16 && H == 64 && F2 <= 128 && F % 4 == 0;
-  static constexpr int NB = F / 4;                 // conv wavefronts (4 channels each)
-  static constexpr int NW = NB + 1;                // + the head wavefront
+  static constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, G = Sh::G;
+  static constexpr int LPC = ((P + 1 + 3) / 4) * 4;   // lanes per channel: P rows + at least one zero-padding lane, whole quads
+  static constexpr int CPW = v2_pick_cpw(F, LPC);     // channels per wave
+  static constexpr int NQ = LPC / 4;                  // quad partials per channel sum
+  static constexpr int NB = F / CPW;                  // conv wavefronts
+  static constexpr int NW = NB + 1;                   // + the head wavefront
   static constexpr int NT = NW * 64;
-  // private window slice of a wave: [P rows][ROWQ 16-byte chunks]; a row holds P pixels x Cg bands (+ one pad chunk
-  // where needed so that the row stride in chunks is odd: 16 row-lanes x ds_read_b128 then hit 64 distinct banks)
+  // window in LDS: the patch image [P*P pixels][CS], pixel-major like the scene, so that a 1-KiB gather piece is (mostly)
+  // 1 KiB of contiguous scene bytes; CS = C + the padding that spreads the row-lanes' ds_read_b128 over the banks
   static constexpr int QC = Cg / 4;
-  static constexpr int ROWQ0 = P * QC;
-  static constexpr int ROWQ = ROWQ0 | 1;
-  static constexpr int ROWF = ROWQ * 4;
-  static constexpr int SLQ = P * ROWQ;
-  static constexpr int NPC = (SLQ + 63) / 64;      // 1-KiB LDS-DMA pieces per wave
-  static constexpr int SLICE = NPC * 256;          // floats
-  static constexpr int AR0 = P * C2;               // aux floats per patch row
-  static constexpr int RSP = ((P + 3) / 4) * 4;    // row stride of the staged pooling profile
-  static constexpr int W1TS = ((H / 4) | 1) * 4;   // row stride of the staged TRANSPOSED fc1.weight [2F][W1TS] (odd chunk count)
-  static constexpr int W2S = ((H / 4) | 1) * 4;    // row stride of the staged fc2.weight
+  static constexpr int CS = v2_pick_cs(Sh::C, P, Cg, LPC, CPW, Sh::M, NB);
+  static constexpr int XF = ((P2 * CS + 255) / 256) * 256;   // floats, whole pieces
+  static constexpr int NPIECE = XF / 256;
+  static constexpr int NK = (NPIECE + NW - 1) / NW;   // pieces per wave (all NW waves gather)
+  static constexpr int AR0 = P * C2;                  // aux floats per patch row
+  static constexpr int RSP = ((P + 3) / 4) * 4;       // row stride of the staged pooling profile
+  static constexpr int W2S = ((H / 4) | 1) * 4;       // row stride of the staged fc2.weight
+  static constexpr int ZS = ((F2 + 15) / 16) * 16;    // stride of one quad-partial vector of pooled features
   static constexpr int oX = 0;
-  static constexpr int oTh = oX + NB * SLICE;      // conv part of theta, parameter order
-  static constexpr int oPool = oTh + Sh::SLAB;     // pooling profile [P][RSP]
-  static constexpr int oW1T = oPool + P * RSP;     // fc1.weight transposed [2F][W1TS]  (training: dz on the conv waves)
-  static constexpr int oZ = oW1T + F2 * W1TS;      // pooled features, double buffered (eval runs ahead of the head)
-  static constexpr int oHv = oZ + 2 * 128;         // h [H]
-  static constexpr int oDl = oHv + H;              // dlogits [KMAX]
-  static constexpr int oDh = oDl + KMAX;           // dh [H]
-  static constexpr int oBR = oDh + H;              // [F][16] unit gradients of the aux branch, parked while the primary branch runs
-  static constexpr int oSlab = oBR + F * 16;       // [SLAB] this workgroup's weight-gradient slab row, accumulated over its patches
-  static constexpr int oW2 = oSlab + Sh::SLAB;     // fc2.weight [K rounded up to 4][W2S]  (run-time K)
+  static constexpr int oTh = oX + XF;                 // conv part of theta, parameter order
+  static constexpr int oPool = oTh + Sh::SLAB;        // pooling profile [P][RSP]
+  static constexpr int oW1T = oPool + P * RSP;        // fc1.weight transposed [2F][H]  (training: dz on the conv waves)
+  static constexpr int oZ = oW1T + (TR ? F2 * H : 0); // pooled features [ZS]; eval: two buffers (it runs ahead of the head)
+  static constexpr int NZB = TR ? 1 : 2;
+  static constexpr int oZP = oZ + NZB * ZS;           // per conv wave: the quad partials of its channels' pooled features [NB][ZPW]
+  static constexpr int ZPW = ((2 * CPW * NQ + 15) / 16) * 16;
+  static constexpr int oHv = oZP + NB * ZPW;          // h [H]
+  static constexpr int oDl = oHv + H;                 // dlogits [KMAX]
+  static constexpr int oDh = oDl + KMAX;              // dh [H]
+  static constexpr int oDz = oDh + H;                 // dL/dz [ZS]
+  static constexpr int oSlab = oDz + (TR ? ZS : 0);   // [NQ][SLAB] UNIT weight gradients of the current patch, one copy per quad partial
+  static constexpr int NCOPY = TR ? NQ : 0;
+  static constexpr int oW2 = oSlab + NCOPY * Sh::SLAB;   // fc2.weight [K rounded up to 4][W2S]  (run-time K)
   static constexpr int FIXED = oW2;
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
+  static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
+                             Sh::SLAB / 4 <= NT && P * RSP <= NT && NK <= 16;
 };
 
 // LDS reads the compiler's waitcnt pass cannot see.  It orders EVERY LDS access it knows of behind all outstanding
@@ -121,24 +191,31 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ float relu_lim(float x, float lim) { return __builtin_amdgcn_fmed3f(x, 0.f, lim); }   // lim = +inf: ReLU; 0: 0
 
-__device__ __forceinline__ float dpp_row_above(float v) {   // value held by lane-1 of the 16-lane row (patch row r-1); 0 at r = 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+__device__ __forceinline__ float lane_above(float v) {   // value held by lane-1 (patch row r-1, or the previous channel's padding lane); 0 at lane 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));   // wave_shr:1
 }
-__device__ __forceinline__ float dpp_row_below(float v) {   // lane+1 (patch row r+1); 0 at r = 15
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
+__device__ __forceinline__ float lane_below(float v) {   // lane+1 (patch row r+1, or this channel's padding lane); 0 at lane 63
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));   // wave_shl:1
+}
+__device__ __forceinline__ float quad_sum(float v) {     // over the 4 lanes of a quad, result in each of them
+  v = DMF_DPP_ADD(v, 0xB1);     // quad_perm [1,0,3,2]
+  v = DMF_DPP_ADD(v, 0x4E);     // quad_perm [2,3,0,1]
+  return v;
 }
 
 // Depthwise 3x3 (zero pad 1) + ReLU + anchor pooling of one channel row, and — TRAIN — its backward for a UNIT
 // gradient on the pooled scalar: dY2 = [y2 > 0] * pool.  A lane holds row r of its channel; rows r-1 / r+1 are the
-// neighbouring lanes.  Lanes r >= P carry y1 = 0 and pool = 0, which is exactly the zero padding.
-//   z  : pooled partial of this row (caller reduces over the 16 row lanes)
+// neighbouring lanes.  Padding lanes carry y1 = 0 and a closed gate, which is exactly the zero padding.
+//   z  : pooled partial of this row (caller sums over the channel's lanes)
 //   dw : unit dL/dW2[u][v] partial, db: unit dL/db2 partial, dy: unit dL/dY1 of this row (through Y1's ReLU)
-template <int P, bool TR>
-__device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
-                                         float& z, float (&dw)[9], float& db, float (&dy)[P]) {
-  float y1u[P], y1d[P], gq[P];
+template <int P>
+struct ConvRows { float y1u[P], y1d[P], gq[P]; };
+
+template <int P>
+__device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
+                                             ConvRows<P>& t, float& z) {
 #pragma unroll
-  for (int c = 0; c < P; ++c) { y1u[c] = dpp_row_above(y1c[c]); y1d[c] = dpp_row_below(y1c[c]); }
+  for (int c = 0; c < P; ++c) { t.y1u[c] = lane_above(y1c[c]); t.y1d[c] = lane_below(y1c[c]); }
   z = 0.f;
 #pragma unroll
   for (int c = 0; c < P; ++c) {
@@ -147,74 +224,86 @@ __device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)
     for (int v = 0; v < 3; ++v) {
       const int cc = c + v - 1;
       if (cc >= 0 && cc < P) {
-        y = fmaf(w[v], y1u[cc], y);
+        y = fmaf(w[v], t.y1u[cc], y);
         y = fmaf(w[3 + v], y1c[cc], y);
-        y = fmaf(w[6 + v], y1d[cc], y);
+        y = fmaf(w[6 + v], t.y1d[cc], y);
       }
     }
-    gq[c] = y > 0.f ? pw[c] : 0.f;
-    z = fmaf(gq[c], y, z);
-  }
-  if constexpr (TR) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dw[k] = 0.f;
-    db = 0.f;
-#pragma unroll
-    for (int c = 0; c < P; ++c) {
-      db += gq[c];
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const int cc = c + v - 1;
-        if (cc >= 0 && cc < P) {
-          dw[v] = fmaf(gq[c], y1u[cc], dw[v]);
-          dw[3 + v] = fmaf(gq[c], y1c[cc], dw[3 + v]);
-          dw[6 + v] = fmaf(gq[c], y1d[cc], dw[6 + v]);
-        }
-      }
-    }
-    // dY1(r,c) = [y1 > 0] * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1): u = 0 pairs with the row below, u = 2 with the row above
-    float gu[P], gd[P];
-#pragma unroll
-    for (int c = 0; c < P; ++c) { gu[c] = dpp_row_above(gq[c]); gd[c] = dpp_row_below(gq[c]); }
-#pragma unroll
-    for (int c = 0; c < P; ++c) {
-      float s = 0.f;
-#pragma unroll
-      for (int v = 0; v < 3; ++v) {
-        const int cc = c - v + 1;
-        if (cc >= 0 && cc < P) {
-          s = fmaf(w[v], gd[cc], s);
-          s = fmaf(w[3 + v], gq[cc], s);
-          s = fmaf(w[6 + v], gu[cc], s);
-        }
-      }
-      dy[c] = y1c[c] > 0.f ? s : 0.f;
-    }
+    t.gq[c] = y > 0.f ? pw[c] : 0.f;
+    z = fmaf(t.gq[c], y, z);
   }
 }
 
-// The window gather: NPC 1-KiB pieces of LDS-DMA, lane l of piece i reads 16 bytes at base + off[i] into slice + 1024 i + 16 l.
-// It goes through the BUFFER form (buffer_load_dwordx4 ... lds): with the FLAT-encoded global_load_lds the compiler's
-// waitcnt pass marks a "pending flat" access and turns EVERY later vmcnt / lgkmcnt dependency into a wait for zero — the
-// aux rows (loaded just before) would then wait for the whole window.  (Device pass only: the buffer-resource type does
-// not exist in the host pass, which needs nothing but the kernel's stub.)
-template <int NPC>
-__device__ __forceinline__ void gather_slice(const float* base, float* slice, const int (&off)[NPC]) {
+template <int P>
+__device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float (&w)[9], const ConvRows<P>& t,
+                                             float (&dw)[9], float& db, float (&dy)[P]) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dw[k] = 0.f;
+  db = 0.f;
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    db += t.gq[c];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int cc = c + v - 1;
+      if (cc >= 0 && cc < P) {
+        dw[v] = fmaf(t.gq[c], t.y1u[cc], dw[v]);
+        dw[3 + v] = fmaf(t.gq[c], y1c[cc], dw[3 + v]);
+        dw[6 + v] = fmaf(t.gq[c], t.y1d[cc], dw[6 + v]);
+      }
+    }
+  }
+  // dY1(r,c) = [y1 > 0] * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1): u = 0 pairs with the row below, u = 2 with the row above
+  float gu[P], gd[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) { gu[c] = lane_above(t.gq[c]); gd[c] = lane_below(t.gq[c]); }
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int cc = c - v + 1;
+      if (cc >= 0 && cc < P) {
+        s = fmaf(w[v], gd[cc], s);
+        s = fmaf(w[3 + v], t.gq[cc], s);
+        s = fmaf(w[6 + v], gu[cc], s);
+      }
+    }
+    dy[c] = y1c[c] > 0.f ? s : 0.f;
+  }
+}
+
+template <int P, bool TR>
+__device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
+                                         float& z, float (&dw)[9], float& db, float (&dy)[P]) {
+  ConvRows<P> t;
+  conv_row_fwd<P>(y1c, w, bias, pw, t, z);
+  if constexpr (TR) conv_row_bwd<P>(y1c, w, t, dw, db, dy);
+}
+
+// One piece of LDS-DMA: lane l reads BYTES (4 or 16) bytes at base + soff + voff into lds + BYTES l (lanes with voff < 0 are
+// masked off).  BUFFER form (buffer_load_dword[x4] ... lds): see the header comment.  (Device pass only: the buffer-resource
+// type does not exist in the host pass, which needs nothing but the kernel's stub.)
+template <int BYTES>
+__device__ __forceinline__ void dma_piece(const float* base, int soff, int voff, float* lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
-#pragma unroll
-  for (int i = 0; i < NPC; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(slice + i * 256), 16, off[i], 0, 0, 0);
+  if (voff >= 0) {
+    if constexpr (BYTES == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 4, voff, soff, 0, 0);
+  }
 #endif
 }
+__device__ __forceinline__ void gather_piece(const float* base, int soff, int voff, float* lds) { dma_piece<16>(base, soff, voff, lds); }
 
 // INMODE: dmf_input.mode, compile time — with a run-time branch the waitcnt pass merges the two paths' states at the
 // join and waits vmcnt(0) there, i.e. for the whole window, before the aux phase.
 template <class Sh, int MODE, int INMODE>
 __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
-  using V = V2<Sh>;
-  constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, QC = V::QC;
   constexpr bool TR = (MODE != MODE_FWD);
+  using V = V2<Sh, TR>;
+  constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, QC = V::QC;
+  constexpr int LPC = V::LPC, CPW = V::CPW, NQ = V::NQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -228,83 +317,184 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   float* sDh = smem + V::oDh;
   float* sSlab = smem + V::oSlab;
   VSTAMP_DECL;
-  VSTAMP(0);
+  VSTAMP_RT(12);
+  VSTAMP_W(0);
+  // the head wave is the youngest wave of its SIMD: at equal priority it only gets the issue slots its two conv waves leave,
+  // and every barrier then waits for it
+  if (wave == V::NB) __builtin_amdgcn_s_setprio(3);
+  else if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
+                                                          // wave of a SIMD wins every arbitration and the younger one trails it
   if (MODE == MODE_TRAIN && a.adam_step != nullptr && blockIdx.x == 0 && tid == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? ((cint*)a.in.cursor)[0] * B : 0;     // epoch-plan offset of this batch
-  // Patch-invariant tables -> LDS, one 16-byte piece (and one pooling weight) per thread: the conv part of theta in
-  // parameter order, the pooling profile in 16-byte-aligned rows.  A lane's per-channel constants then come from LDS
-  // (a handful of reads) instead of ~45 four-lane-wide global loads per wave queued in front of the gather.
-  static_assert(Sh::SLAB / 4 <= V::NT && P * V::RSP <= V::NT, "one staging piece per thread");
-  {
-    float4 tv = make_float4(0.f, 0.f, 0.f, 0.f);
-    float pv = 0.f;
-    const int pr = tid / V::RSP, pc = tid - pr * V::RSP;
-    if (tid < Sh::SLAB / 4) tv = *reinterpret_cast<const float4*>(th + 4 * (tid < Sh::NCONV / 4 ? tid : 0));
-    if (tid < P * V::RSP && pc < P) pv = a.pool[pr * P + pc];
-    if (tid < Sh::SLAB / 4) *reinterpret_cast<float4*>(sTh + 4 * tid) = tv;
-    if (tid < P * V::RSP) sPool[tid] = pv;
-    if (TR && tid < Sh::SLAB / 4) *reinterpret_cast<float4*>(sSlab + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // first patch's coordinates: requested before anything else (kernarg -> coordinates -> gather is the kernel's longest
+  // dependent chain of memory round trips; the table staging below runs under it)
+  int xn = 0, yn = 0;
+  if (INMODE == 1 && (int)blockIdx.x < B) {
+    xn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x) + 1];
   }
+  if constexpr (TR) {   // the slab rows' padding beyond the last parameter is copied out too: keep it zero
+    if (tid < Sh::SLAB - Sh::NCONV) {
+#pragma unroll
+      for (int c = 0; c < V::NCOPY; ++c) sSlab[c * Sh::SLAB + Sh::NCONV + tid] = 0.f;
+    }
+  }
+  // ---- patch-invariant tables -> LDS by LDS-DMA (no registers, no wait here): the conv part of theta in parameter order
+  //      (NTHP 1-KiB pieces) and the pooling profile in 16-byte-aligned rows (NPLP 256-byte pieces); piece q is issued by
+  //      wave q % NW.  Each wave waits for its own pieces (stage_wait) before the barrier in front of the first gather.
+  {
+    constexpr int NTHP = (Sh::SLAB / 4 + 63) / 64, NPLP = (P * V::RSP + 63) / 64;
+#pragma unroll
+    for (int q = 0; q < NTHP + NPLP; ++q) {
+      if (q % V::NW != wave) continue;
+      if (q < NTHP) {
+        const int c4 = q * 64 + lane;                      // 16-byte piece of theta
+        dma_piece<16>(th, 0, c4 < Sh::SLAB / 4 ? (c4 < Sh::NCONV / 4 ? c4 : 0) * 16 : -1, sTh + q * 256);
+      } else {
+        const int t = (q - NTHP) * 64 + lane;              // element of the padded pooling table
+        const int pr = t / V::RSP, pc = t - pr * V::RSP;
+        dma_piece<4>(a.pool, 0, (t < P * V::RSP && pc < P) ? (pr * P + pc) * 4 : -1, sPool + (q - NTHP) * 64);
+      }
+    }
+  }
+  // (inline asm: the compiler must not count this against later loads — it orders visible LDS accesses behind the staging
+  // pieces with counted waits of its own)
+#define DMF_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
   static_assert(Sh::NCONV % 4 == 0, "conv parameters in whole 16-byte pieces");
+  // This wave's share of the gather: pieces p = wave + k NW of the window image.  Lane l of piece p holds image floats
+  // n = 256 p + 4 l .. + 3 = pixel n / CS, bands n % CS ..; its scene offset is ((row Wp + col) C + band) floats.
+  auto issue_gather = [&](int x, int y) {
+    const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * Sh::C;
+    const int rowskip = (a.in.Wp - P) * Sh::C;               // floats between the end of a window row and the start of the next
+#pragma unroll
+    for (int k = 0; k < V::NK; ++k) {
+      const int p = wave + k * V::NW;
+      const int n = 256 * p + 4 * lane;
+      int off;
+      if constexpr (V::CS == Sh::C) {                        // unpadded image: window rows are contiguous runs of the scene
+        const int pr = n / (P * Sh::C);
+        off = (n + pr * rowskip) * 4;
+        if (n >= P2 * Sh::C) off = -1;
+      } else {
+        const int pix = n / V::CS, band = n - pix * V::CS;
+        const int pr = pix / P;
+        off = (pix * Sh::C + band + pr * rowskip) * 4;
+        if (pix >= P2 || band >= Sh::C) off = -1;
+      }
+      if (p >= V::NPIECE) off = -1;
+      gather_piece(base, 0, off, smem + V::oX + (p < V::NPIECE ? p : 0) * 256);
+    }
+  };
+
+  // Behind barrier 2, all waves: dL/dz[i] = sum_j fc1.weight[j][i] dh[j] (4 lanes per i), then the workgroup's slab row =
+  // sum of the quad copies of the UNIT gradients x dL/dz of each element's channel, in one coalesced pass (streaming stores:
+  // next read by the reduce kernel).  A workgroup that walks several patches accumulates in its (L2-resident) global row.
+  int dzix = 0;                                            // channel (dz index) of each of this thread's 4 slab elements, 8 bits each
+  if constexpr (TR) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = 4 * tid + e;
+      int ix = 0;
+      if (p < Sh::oA1b) ix = p / Cg;
+      else if (p < Sh::oA2w) ix = p - Sh::oA1b;
+      else if (p < Sh::oA2b) ix = (p - Sh::oA2w) / 9;
+      else if (p < Sh::oB1w) ix = p - Sh::oA2b;
+      else if (p < Sh::oB1b) ix = F + (p - Sh::oB1w) / Sh::TB;
+      else if (p < Sh::oB2w) ix = F + p - Sh::oB1b;
+      else if (p < Sh::oB2b) ix = F + (p - Sh::oB2w) / 9;
+      else if (p < Sh::NCONV) ix = F + p - Sh::oB2b;
+      dzix |= ix << (8 * e);
+    }
+  }
+  auto scale_and_store = [&](int it) {
+    float* sDz = smem + V::oDz;
+    if (tid < 4 * F2) {
+      const int i = tid >> 2, m = tid & 3;
+      float d = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 dhv = *reinterpret_cast<const float4*>(sDh + 16 * m + 4 * q);
+        const float4 wv = *reinterpret_cast<const float4*>(smem + V::oW1T + i * H + 16 * m + 4 * q);
+        d = fmaf(wv.x, dhv.x, fmaf(wv.y, dhv.y, fmaf(wv.z, dhv.z, fmaf(wv.w, dhv.w, d))));
+      }
+      d = quad_sum(d);
+      if (m == 0) sDz[i] = d;
+    }
+    LDS_BARRIER();                                       // barrier 3: dz complete
+    if (tid < Sh::SLAB / 4) {
+      float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * tid);
+#pragma unroll
+      for (int c = 1; c < V::NCOPY; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * tid);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      v.x *= sDz[dzix & 255]; v.y *= sDz[(dzix >> 8) & 255]; v.z *= sDz[(dzix >> 16) & 255]; v.w *= sDz[(dzix >> 24) & 255];
+      float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB + 4 * tid;
+      if (it > 0) {
+        const float4 o = *reinterpret_cast<const float4*>(slab);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      __builtin_nontemporal_store(v.x, slab);
+      __builtin_nontemporal_store(v.y, slab + 1);
+      __builtin_nontemporal_store(v.z, slab + 2);
+      __builtin_nontemporal_store(v.w, slab + 3);
+    }
+  };
+  static_assert(!TR || (4 * F2 <= V::NT && F2 <= 255), "dz mapping");
 
   if (wave < V::NB) {
     // =============================================================================== conv wavefronts
-    const int ch = lane >> 4, r = lane & 15;
-    const int f = 4 * wave + ch;
-    const bool act = r < P;
-    const int rc = act ? r : P - 1;
-    // Lanes of rows >= P are the zero padding below the patch: their Y1 is forced to 0 (ReLU limit 0 instead of +inf) and
-    // their depthwise bias is hugely negative, so their ReLU gates are closed (pooling weight 0, no gradient) whatever
+    // A lane's roles are re-derived from an opaque copy of its lane id at the top of every phase: kept live across the
+    // whole patch loop they are spilled around the register-hungry phases, and a scratch reload in front of the gather
+    // costs a wait for every outstanding load.
+    //   seg, r : channel slot of the wave, patch row;  qd: which quad partial of its channel this lane's quad forms;
+    //   lead   : one lane per quad owns the quad's results
+    // Padding lanes are the zero padding around the patch rows: their Y1 is forced to 0 (ReLU limit 0 instead of +inf)
+    // and their depthwise bias is hugely negative, so their ReLU gates are closed (pooling weight 0, no gradient) whatever
     // their (clamped-row) inputs are.
-    const float lim = act ? INFINITY : 0.f;
-    const int g = (4 * wave) / Sh::M;                         // band group of this wave's channels (wave-uniform)
-    float* sX = smem + V::oX + wave * V::SLICE;
-    const float* xr = sX + rc * V::ROWF;
-    const unsigned aTh = lds_addr(sTh) + 4u * (unsigned)f;           // hidden-read bases (bytes)
-    const unsigned aPool = lds_addr(sPool) + 4u * (unsigned)(rc * V::RSP);
-    // first patch's coordinates: requested before the offset arithmetic below, which covers their latency
-    int xn = 0, yn = 0;
-    if (INMODE == 1 && (int)blockIdx.x < B) {
-      xn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x) + 1];
-    }
-    // ---- LDS-DMA source offsets of this lane (bytes from the patch's first pixel / this wave's first band);
-    //      lanes that fall on pad chunks or beyond the slice read offset 0 (harmless, in range) into unused LDS
-    int offx[V::NPC];
-    {
-      const int Wp = a.in.Wp;
-#pragma unroll
-      for (int i = 0; i < V::NPC; ++i) {
-        const int n = 64 * i + lane;
-        const int row = n / V::ROWQ, w = n - row * V::ROWQ;
-        const int col = w / QC, q = w - col * QC;
-        const bool ok = row < P && w < V::ROWQ0;
-        offx[i] = ok ? ((row * Wp + col) * Sh::C + 4 * q) * 4 : 0;
-      }
-    }
+#define DMF_ROLES()                                                                  \
+    int l_ = lane; OPAQUE(l_);                                                     \
+    const int seg = l_ / LPC, r = l_ - seg * LPC;                                  \
+    const bool vch = seg < CPW;                                                    \
+    const int f = CPW * wave + (vch ? seg : CPW - 1);                              \
+    const bool act = vch && r < P;                                                 \
+    const int rc = r < P ? r : P - 1;                                              \
+    const int qd = r >> 2;                                                         \
+    const bool lead = vch && (r & 3) == 0;                                         \
+    const float lim = act ? INFINITY : 0.f;                                        \
+    const float* xr = smem + V::oX + rc * P * V::CS + (f / Sh::M) * Cg;             \
+    float* sl = sSlab + qd * Sh::SLAB;                                             \
+    (void)lead; (void)lim; (void)xr; (void)sl; (void)qd; (void)act
     VSTAMP(1);
 
     int it = 0;
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
-      // ------------------------------------------------------------------ aux row -> registers, window -> LDS slice
+      // ------------------------------------------------------------------ aux row -> registers, window -> LDS
       float ax[V::AR0];
+      float zb;
+      {
+      DMF_ROLES();
+      const unsigned aTh = lds_addr(sTh) + 4u * (unsigned)f;           // hidden-read bases (bytes)
+      const unsigned aPool = lds_addr(sPool) + 4u * (unsigned)(rc * V::RSP);
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
-        {   // the next patch's coordinates, a whole patch ahead of their use
-          const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
-          xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
-        }
+        if (it == 0) DMF_STAGE_WAIT();                       // this wave's staging pieces (issued at kernel entry) have landed
         const float* __restrict__ srcB = a.in.sceneB + ((size_t)(x + rc) * a.in.WpB + y) * C2;
 #pragma unroll
         for (int i = 0; i < V::AR0; ++i) ax[i] = srcB[i];
-        // barrier 0 (first patch): the staged tables are complete — and every wave's aux-row loads are in the memory
-        // pipeline AHEAD of every wave's window pieces (requests of one CU are served in issue order: an aux row issued
-        // behind another wave's 10 KiB of gather would only arrive with the window)
+        // barrier X (first patch): the offset table and the staged tables are complete, and every wave's aux-row loads are
+        // in the memory pipeline AHEAD of every wave's window pieces (requests of one CU are served in issue order: an aux
+        // row queued behind 100 KiB of gather arrives with the window)
+        VSTAMP(11);
         if (it == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the scheduler must not sink the gather below the aux phase (nor hoist that phase above it): everything older
-        // is issued, then the NPC pieces, then the aux phase runs under them
+        // the scheduler must not sink the gather below the aux phase (nor hoist that phase above it)
         __builtin_amdgcn_sched_barrier(0);
-        gather_slice<V::NPC>(a.in.sceneA + ((size_t)x * a.in.Wp + y) * Sh::C + g * Cg, sX, offx);
+        issue_gather(x, y);
         __builtin_amdgcn_sched_barrier(0);
+
+        {   // the next patch's coordinates, a whole patch ahead of their use (behind barrier 0: its lgkmcnt wait would cover them)
+          const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
+          xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
+        }
       } else {
         // materialised band-major patches (the reference dataloader's tensors; test / drop-in path)
         const float* __restrict__ srcB = a.in.b + (size_t)(boff + b) * C2 * P2;
@@ -312,21 +502,17 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         for (int c = 0; c < P; ++c)
 #pragma unroll
           for (int k = 0; k < C2; ++k) ax[c * C2 + k] = srcB[k * P2 + rc * P + c];
-        const float* __restrict__ srcA = a.in.a + ((size_t)(boff + b) * Sh::C + g * Cg) * P2;
-        for (int e = lane; e < Cg * P2; e += 64) {
-          const int j = e / P2, pix = e - j * P2;
-          const int pr = pix / P, pc = pix - pr * P;
-          sX[pr * V::ROWF + pc * Cg + j] = srcA[e];
+        if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // barrier X
+        const float* __restrict__ srcA = a.in.a + (size_t)(boff + b) * Sh::C * P2;
+        for (int e = tid; e < Sh::C * P2; e += V::NB * 64) {
+          const int cb = e / P2, pix = e - cb * P2;
+          smem[V::oX + pix * V::CS + cb] = srcA[e];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (it == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // barrier 0: the staged tables are complete
       }
       VSTAMP(2);
 
       // ------------------------------------------------------------------ aux branch, under the window gather
-      float zb, dwb[9], dbb = 0.f, dwl[C2], dbl = 0.f;
+      float dwb[9], dbb = 0.f, dwl[C2], dbl = 0.f;
       {
         float w2b[9], wl[C2], pw[P], b2b, bl;
         // (the channel-dependent part of an offset is in the base address, the rest is an instruction immediate)
@@ -356,7 +542,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           y1b[c] = relu_lim(v, lim);
         }
         conv_row<P, TR>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb);
-        zb = sum16(zb);
+        zb = quad_sum(zb);
         if constexpr (TR) {
 #pragma unroll
           for (int k = 0; k < C2; ++k) dwl[k] = 0.f;
@@ -367,27 +553,30 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
             for (int k = 0; k < C2; ++k) dwl[k] = fmaf(dyb[c], ax[c * C2 + k], dwl[k]);
           }
 #pragma unroll
-          for (int k = 0; k < 9; ++k) dwb[k] = sum16(dwb[k]);
-          dbb = sum16(dbb);
-          dbl = sum16(dbl);
+          for (int k = 0; k < 9; ++k) dwb[k] = quad_sum(dwb[k]);
+          dbb = quad_sum(dbb);
+          dbl = quad_sum(dbl);
 #pragma unroll
-          for (int k = 0; k < C2; ++k) dwl[k] = sum16(dwl[k]);
+          for (int k = 0; k < C2; ++k) dwl[k] = quad_sum(dwl[k]);
         }
       }
       VSTAMP(3);
-      // park the aux branch's unit gradients (the first LDS access the compiler sees behind the gather: it waits for the
-      // wave's own LDS-DMA here, which the primary branch needs anyway)
+      // the aux branch's unit gradients go to this quad's copy of the slab row (the first LDS access the compiler sees
+      // behind the gather: it waits for the wave's own LDS-DMA here), then barrier W: every wave's pieces have landed
       if constexpr (TR) {
-        float* br = smem + V::oBR + f * 16;
-        if (r == 0) {
+        if (lead) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) br[k] = dwb[k];
-          br[9] = dbb;
-          br[10] = dbl;
+          for (int k = 0; k < 9; ++k) sl[Sh::oB2w + f * 9 + k] = dwb[k];
+          sl[Sh::oB2b + f] = dbb;
+          sl[Sh::oB1b + f] = dbl;
 #pragma unroll
-          for (int k = 0; k < C2; ++k) br[11 + k] = dwl[k];
+          for (int k = 0; k < C2; ++k) sl[Sh::oB1w + f * C2 + k] = dwl[k];
         }
       }
+      }
+      __syncthreads();                                       // barrier W (vmcnt(0) + s_barrier)
+      VSTAMP(4);
+      DMF_ROLES();
 
       // ------------------------------------------------------------------ primary branch
       float w2a[9], pw[P], b2a;
@@ -416,29 +605,45 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
 #pragma unroll
         for (int c = 0; c < P; ++c) ap[c] = (v2f){b1, 0.f};
 #pragma unroll
-        for (int c = 0; c < P; ++c)
+        for (int c = 0; c < P; ++c) {
+          if (c % 3 == 0 && c > 0) __builtin_amdgcn_sched_barrier(0);   // bounds the window reads the scheduler keeps in flight (registers)
 #pragma unroll
           for (int q = 0; q < QC; ++q) {
-            const float4 xv = *reinterpret_cast<const float4*>(xr + c * Cg + 4 * q);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + c * V::CS + 4 * q);
             ap[c] = pk_fma(w1p[2 * q], (v2f){xv.x, xv.y}, ap[c]);
             ap[c] = pk_fma(w1p[2 * q + 1], (v2f){xv.z, xv.w}, ap[c]);
           }
+        }
 #pragma unroll
         for (int c = 0; c < P; ++c) y1a[c] = relu_lim(ap[c].x + ap[c].y, lim);
       }
-      VSTAMP(4);
       float za, dwa[9], dba = 0.f, dya[P];
-      conv_row<P, TR>(y1a, w2a, act ? b2a : -1e30f, pw, za, dwa, dba, dya);
-      za = sum16(za);
-      {
-        float* zbuf = sZ + (TR ? 0 : (it & 1) * 128);
-        if (r == 0) { zbuf[f] = za; zbuf[F + f] = zb; }
+      ConvRows<P> ta;
+      conv_row_fwd<P>(y1a, w2a, act ? b2a : -1e30f, pw, ta, za);
+      za = quad_sum(za);
+      {   // pooled features of the wave's channels: quad partials -> wave-private scratch -> one lane per value sums NQ of them
+        float* zp = smem + V::oZP + wave * V::ZPW;
+        if (lead) { zp[(2 * seg) * NQ + qd] = za; zp[(2 * seg + 1) * NQ + qd] = zb; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 2 * CPW) {
+          float zs = 0.f;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) zs += zp[lane * NQ + q];
+          float* zbuf = sZ + (TR ? 0 : (it & 1)) * V::ZS;
+          zbuf[((lane & 1) ? F : 0) + CPW * wave + (lane >> 1)] = zs;
+        }
       }
-      LDS_BARRIER();                                     // barrier 1: z complete
+      LDS_BARRIER();                                     // barrier 1: pooled features complete
       VSTAMP(5);
       if constexpr (!TR) continue;
+      // spat_a's unit backward runs BEHIND barrier 1: the head starts a conv backward earlier, and its chain of LDS round
+      // trips (fc1 -> fc2 -> softmax -> dh) begins while the conv waves execute pure vector work instead of queueing behind
+      // their window reads
+      conv_row_bwd<P>(y1a, w2a, ta, dwa, dba, dya);
 
-      // ------------------------------------------------------------------ unit gradients of spec_a from the still-resident slice
+      // ------------------------------------------------------------------ unit gradients of spec_a from the still-resident window
       float acc[Cg], db1 = 0.f;
       {
         v2f gp[Cg / 2];
@@ -446,11 +651,12 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         for (int j = 0; j < Cg / 2; ++j) gp[j] = (v2f){0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < P; ++c) {
+          if (c % 3 == 0 && c > 0) __builtin_amdgcn_sched_barrier(0);
           db1 += dya[c];
           const v2f d2 = (v2f){dya[c], dya[c]};
 #pragma unroll
           for (int q = 0; q < QC; ++q) {
-            const float4 xv = *reinterpret_cast<const float4*>(xr + c * Cg + 4 * q);
+            const float4 xv = *reinterpret_cast<const float4*>(xr + c * V::CS + 4 * q);
             gp[2 * q] = pk_fma(d2, (v2f){xv.x, xv.y}, gp[2 * q]);
             gp[2 * q + 1] = pk_fma(d2, (v2f){xv.z, xv.w}, gp[2 * q + 1]);
           }
@@ -460,74 +666,24 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       }
       VSTAMP(6);
 #pragma unroll
-      for (int j = 0; j < Cg; ++j) acc[j] = sum16(acc[j]);
+      for (int j = 0; j < Cg; ++j) acc[j] = quad_sum(acc[j]);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) dwa[k] = sum16(dwa[k]);
-      dba = sum16(dba);
-      db1 = sum16(db1);
-      // this lane's slice of the two fc1 columns of its channel, fetched before the barrier: dz[i] = sum_j W1[j][i] dh[j]
-      const float4 wta = *reinterpret_cast<const float4*>(smem + V::oW1T + f * V::W1TS + 4 * r);
-      const float4 wtb = *reinterpret_cast<const float4*>(smem + V::oW1T + (F + f) * V::W1TS + 4 * r);
-      float brv[16];                                    // the parked aux-branch unit gradients of this channel
+      for (int k = 0; k < 9; ++k) dwa[k] = quad_sum(dwa[k]);
+      dba = quad_sum(dba);
+      db1 = quad_sum(db1);
+      if (lead) {   // the primary branch's unit gradients -> this quad's slab copy
+        float* so = sl + Sh::oA1w + f * Cg;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(smem + V::oBR + f * 16 + 4 * q);
-        brv[4 * q] = v.x; brv[4 * q + 1] = v.y; brv[4 * q + 2] = v.z; brv[4 * q + 3] = v.w;
+        for (int q = 0; q < QC; ++q) *reinterpret_cast<float4*>(so + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        sl[Sh::oA1b + f] = db1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sl[Sh::oA2w + f * 9 + k] = dwa[k];
+        sl[Sh::oA2b + f] = dba;
       }
       VSTAMP(7);
-      LDS_BARRIER();                                     // barrier 2: dh complete
+      LDS_BARRIER();                                     // barrier 2: dh and the unit gradients complete
       VSTAMP(8);
-      {
-        const float4 dhv = *reinterpret_cast<const float4*>(sDh + 4 * r);
-        float dza = fmaf(wta.x, dhv.x, fmaf(wta.y, dhv.y, fmaf(wta.z, dhv.z, wta.w * dhv.w)));
-        float dzb = fmaf(wtb.x, dhv.x, fmaf(wtb.y, dhv.y, fmaf(wtb.z, dhv.z, wtb.w * dhv.w)));
-        dza = sum16(dza);
-        dzb = sum16(dzb);
-        if (r == 0) {   // scale the unit gradients by dL/dz; one owner lane per slab element (first patch: plain stores)
-          float* so = sSlab + Sh::oA1w + f * Cg;
-          if (it == 0) {
-#pragma unroll
-            for (int q = 0; q < QC; ++q)
-              *reinterpret_cast<float4*>(so + 4 * q) = make_float4(dza * acc[4 * q], dza * acc[4 * q + 1], dza * acc[4 * q + 2], dza * acc[4 * q + 3]);
-            sSlab[Sh::oA1b + f] = dza * db1;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-              sSlab[Sh::oA2w + f * 9 + k] = dza * dwa[k];
-              sSlab[Sh::oB2w + f * 9 + k] = dzb * brv[k];
-            }
-            sSlab[Sh::oA2b + f] = dza * dba;
-            sSlab[Sh::oB2b + f] = dzb * brv[9];
-            sSlab[Sh::oB1b + f] = dzb * brv[10];
-#pragma unroll
-            for (int k = 0; k < C2; ++k) sSlab[Sh::oB1w + f * C2 + k] = dzb * brv[11 + k];
-          } else {
-            float old[Cg + 22 + C2];
-#pragma unroll
-            for (int j = 0; j < Cg; ++j) old[j] = so[j];
-            old[Cg] = sSlab[Sh::oA1b + f];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { old[Cg + 1 + k] = sSlab[Sh::oA2w + f * 9 + k]; old[Cg + 10 + k] = sSlab[Sh::oB2w + f * 9 + k]; }
-            old[Cg + 19] = sSlab[Sh::oA2b + f];
-            old[Cg + 20] = sSlab[Sh::oB2b + f];
-            old[Cg + 21] = sSlab[Sh::oB1b + f];
-#pragma unroll
-            for (int k = 0; k < C2; ++k) old[Cg + 22 + k] = sSlab[Sh::oB1w + f * C2 + k];
-#pragma unroll
-            for (int j = 0; j < Cg; ++j) so[j] = fmaf(dza, acc[j], old[j]);
-            sSlab[Sh::oA1b + f] = fmaf(dza, db1, old[Cg]);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-              sSlab[Sh::oA2w + f * 9 + k] = fmaf(dza, dwa[k], old[Cg + 1 + k]);
-              sSlab[Sh::oB2w + f * 9 + k] = fmaf(dzb, brv[k], old[Cg + 10 + k]);
-            }
-            sSlab[Sh::oA2b + f] = fmaf(dza, dba, old[Cg + 19]);
-            sSlab[Sh::oB2b + f] = fmaf(dzb, brv[9], old[Cg + 20]);
-            sSlab[Sh::oB1b + f] = fmaf(dzb, brv[10], old[Cg + 21]);
-#pragma unroll
-            for (int k = 0; k < C2; ++k) sSlab[Sh::oB1w + f * C2 + k] = fmaf(dzb, brv[11 + k], old[Cg + 22 + k]);
-          }
-        }
-      }
+      scale_and_store(it);
       VSTAMP(9);
     }
   } else {
@@ -537,41 +693,20 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     float* sH = smem + V::oHv;
     float* sDl = smem + V::oDl;
     const int K4 = (K + 3) & ~3;
-    __builtin_amdgcn_s_setprio(3);     // the youngest wave of its SIMD would otherwise only get the issue slots the conv waves leave
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // barrier 0 (staged tables; the conv waves wait for nothing else)
-    // fc1.weight row `lane` stays in registers for fc1; training also stages it transposed for the conv waves' dz (needed
-    // behind barrier 2).  fc2.weight goes to LDS as 16-byte pieces (rows up to K4 zero filled).
-    float4 w1r[F2 / 4];
-#pragma unroll
-    for (int q = 0; q < F2 / 4; ++q) w1r[q] = *reinterpret_cast<const float4*>(th + Sh::oFc1w + lane * F2 + 4 * q);
-    for (int i0 = 0; i0 < K4 / 4; i0 += 4) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = (i0 + u) * 64 + lane, k = idx >> 4;
-        v[u] = (i0 + u < K4 / 4 && k < K) ? *reinterpret_cast<const float4*>(th + Sh::oFc2w + 4 * idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = (i0 + u) * 64 + lane, k = idx >> 4, c4 = idx & 15;
-        if (i0 + u < K4 / 4) *reinterpret_cast<float4*>(sW2 + k * V::W2S + 4 * c4) = v[u];
-      }
-    }
-    const float bh = th[Sh::oFc1b + lane];
-    const float bk = lane < K ? th[Sh::oFc2w + K * H + lane] : 0.f;
-    if constexpr (TR) {
-#pragma unroll
-      for (int q = 0; q < F2 / 4; ++q) {
-        sW1T[(4 * q) * V::W1TS + lane] = w1r[q].x;
-        sW1T[(4 * q + 1) * V::W1TS + lane] = w1r[q].y;
-        sW1T[(4 * q + 2) * V::W1TS + lane] = w1r[q].z;
-        sW1T[(4 * q + 3) * V::W1TS + lane] = w1r[q].w;
-      }
-    }
+    float4 w1r[F2 / 4];                // fc1.weight row `lane`, in registers for fc1 (loaded behind the first gather issue)
+    float bh = 0.f, bk = 0.f;
     VSTAMP(1);
 
     int it = 0;
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
+      VSTAMP(11);
+      if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier X
+      if constexpr (INMODE == 1) {
+        const int x = xn, y = yn;
+        issue_gather(x, y);                              // this wave's share of the window
+        const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
+        xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
+      }
       int label = 0;
       float dlx = 0.f;
       if (MODE == MODE_TRAIN) {
@@ -579,9 +714,40 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         label = label < 0 ? 0 : (label >= K ? K - 1 : label);
       }
       if (MODE == MODE_BWD) dlx = lane < K ? a.dlogits[(size_t)b * K + lane] : 0.f;
-      LDS_BARRIER();                                     // barrier 1: z complete
+      __syncthreads();                                   // barrier W: window complete (this wave's pieces included)
+      VSTAMP(4);
+      if (it == 0) {   // head tables, behind the gather: nobody needs them before barrier 1, and 20 row-strided loads inside
+                       // the gather stream would delay every wave's pieces (one memory pipeline per CU)
+#pragma unroll
+        for (int q = 0; q < F2 / 4; ++q) w1r[q] = *reinterpret_cast<const float4*>(th + Sh::oFc1w + lane * F2 + 4 * q);
+        bh = th[Sh::oFc1b + lane];
+        bk = lane < K ? th[Sh::oFc2w + K * H + lane] : 0.f;
+        for (int i0 = 0; i0 < K4 / 4; i0 += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = (i0 + u) * 64 + lane, k = idx >> 4;
+            v[u] = (i0 + u < K4 / 4 && k < K) ? *reinterpret_cast<const float4*>(th + Sh::oFc2w + 4 * idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = (i0 + u) * 64 + lane, k = idx >> 4, c4 = idx & 15;
+            if (i0 + u < K4 / 4) *reinterpret_cast<float4*>(sW2 + k * V::W2S + 4 * c4) = v[u];
+          }
+        }
+        if constexpr (TR) {
+#pragma unroll
+          for (int q = 0; q < F2 / 4; ++q) {
+            sW1T[(4 * q) * H + lane] = w1r[q].x;
+            sW1T[(4 * q + 1) * H + lane] = w1r[q].y;
+            sW1T[(4 * q + 2) * H + lane] = w1r[q].z;
+            sW1T[(4 * q + 3) * H + lane] = w1r[q].w;
+          }
+        }
+      }
+      LDS_BARRIER();                                     // barrier 1: pooled features complete
       VSTAMP(5);
-      const float* zbuf = sZ + (TR ? 0 : (it & 1) * 128);
+      const float* zbuf = sZ + (TR ? 0 : (it & 1)) * V::ZS;
       // fc1 + ReLU: lane j, its weight row in registers, z broadcast from LDS
       float h;
       {
@@ -594,6 +760,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         h = fmaxf((s0 + s1) + (s2 + s3), 0.f);
       }
       sH[lane] = h;
+      VSTAMP(2);
       float zo0 = 0.f, zo1 = 0.f;                         // this patch's pooled features, for the gradient reduce
       if constexpr (TR) {
         zo0 = zbuf[lane < F2 ? lane : F2 - 1];
@@ -615,6 +782,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         }
         lg = lane < K ? (s0 + s1) + (s2 + s3) : -INFINITY;
       }
+      VSTAMP(3);
       const float mx = wave_max_dpp(lg);
       const unsigned long long bal = __ballot(lg == mx);
       const int pred_b = __ffsll((long long)bal) - 1;              // first maximal index, as torch.max
@@ -630,6 +798,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           dl = dlx;
         }
         sDl[lane] = dl;
+        VSTAMP(6);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -648,9 +817,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         sDh[lane] = dh;
       }
       VSTAMP(7);
-      if constexpr (TR) LDS_BARRIER();                   // barrier 2: dh complete
+      if constexpr (TR) LDS_BARRIER();                   // barrier 2: dh and the unit gradients complete
       VSTAMP(8);
-      // global results leave after the barrier, off the conv waves' critical path
+      if constexpr (TR) scale_and_store(it);
+      // this patch's head vectors for the gradient reduce
       if ((MODE != MODE_BWD || a.logits != nullptr) && lane < K) a.logits[(size_t)b * K + lane] = lg;
       if (a.pred != nullptr && lane == 0) a.pred[b] = pred_b;
       if constexpr (TR) {
@@ -664,19 +834,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       VSTAMP(9);
     }
   }
-  // the workgroup's slab row leaves in one coalesced pass (streaming stores: next read by the reduce kernel)
-  if constexpr (TR) {
-    LDS_BARRIER();
-    float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB;
-    for (int i = tid; i < Sh::SLAB / 4; i += V::NT) {
-      const float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * i);
-      __builtin_nontemporal_store(v.x, slab + 4 * i);
-      __builtin_nontemporal_store(v.y, slab + 4 * i + 1);
-      __builtin_nontemporal_store(v.z, slab + 4 * i + 2);
-      __builtin_nontemporal_store(v.w, slab + 4 * i + 3);
-    }
-  }
-  VSTAMP(10);
+  VSTAMP_W(10);
+  VSTAMP_RT(13);
   VSTAMP_DUMP();
 }
 
@@ -696,10 +855,9 @@ static hipError_t launch_v2_inst(const KArgs& a, int grid, int bytes, hipStream_
 
 template <class Sh>
 static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
-  using V = V2<Sh>;
   const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
   if (grid <= 0) return hipSuccess;
-  const int bytes = V::lds_bytes(a.K);
+  const int bytes = mode == MODE_FWD ? V2<Sh, false>::lds_bytes(a.K) : V2<Sh, true>::lds_bytes(a.K);
   if (bytes > 160 * 1024) return hipErrorInvalidValue;
   const bool gather = a.in.mode == 1;
   switch (mode) {
@@ -718,7 +876,6 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
 using V2HSI = Shape<200, 1, 11, 1, 40, 10, 64>;      // BASELINE configs 1-2
 using V2HSI224 = Shape<224, 3, 11, 1, 32, 8, 64>;    // BASELINE config 4
 using V2Tiny1 = Shape<8, 1, 5, 1, 40, 2, 64>;        // small test scene, equal resolution
-using V2Qua = Shape<4, 1, 16, 1, 40, 1, 64>;         // stage 2 of the two-stage path
 using V2QuaTiny = Shape<4, 1, 5, 1, 40, 1, 64>;
 
 template <class Sh>
@@ -728,19 +885,18 @@ static bool v2_matches(const dmf_shape& s) {
 }
 
 template <class Sh>
-static bool v2_fits(const dmf_shape& s) { return v2_matches<Sh>(s) && V2<Sh>::lds_bytes(s.K) <= 160 * 1024; }
+static bool v2_fits(const dmf_shape& s) { return v2_matches<Sh>(s) && V2<Sh, true>::lds_bytes(s.K) <= 160 * 1024; }
 
 int patch_v2_supported(const dmf_shape& s, int mode) {
   if (mode != MODE_FWD && mode != MODE_TRAIN && mode != MODE_BWD) return 0;
   if (s.K < 1 || s.K > KMAX || s.attention) return 0;
-  return v2_fits<V2HSI>(s) || v2_fits<V2HSI224>(s) || v2_fits<V2Tiny1>(s) || v2_fits<V2Qua>(s) || v2_fits<V2QuaTiny>(s);
+  return v2_fits<V2HSI>(s) || v2_fits<V2HSI224>(s) || v2_fits<V2Tiny1>(s) || v2_fits<V2QuaTiny>(s);
 }
 
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
   if (v2_matches<V2HSI>(s)) return launch_v2<V2HSI>(mode, a, st);
   if (v2_matches<V2HSI224>(s)) return launch_v2<V2HSI224>(mode, a, st);
   if (v2_matches<V2Tiny1>(s)) return launch_v2<V2Tiny1>(mode, a, st);
-  if (v2_matches<V2Qua>(s)) return launch_v2<V2Qua>(mode, a, st);
   if (v2_matches<V2QuaTiny>(s)) return launch_v2<V2QuaTiny>(mode, a, st);
   return hipErrorInvalidValue;
 }
