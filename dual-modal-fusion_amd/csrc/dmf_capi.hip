@@ -231,6 +231,16 @@ int32_t dmf_shape_supported(const dmf_shape* s) {
   return 0;
 }
 
+static bool force_v1() {
+  static const bool f = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
+  return f;
+}
+
+int32_t dmf_patch_variant(const dmf_shape* s, int32_t mode) {
+  if (s == nullptr || !patch_shape_supported(*s)) return 0;
+  return (!force_v1() && !s->attention && patch_v2_supported(*s, mode)) ? 2 : 1;
+}
+
 int32_t dmf_param_layout(const dmf_shape* s, int64_t offsets[17]) {
   if (s == nullptr || offsets == nullptr) return fail("%s", "null argument");
   const Layout L = layout_of(*s);
@@ -280,8 +290,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
     a.ws_dl = ws + w.dl;
   }
   // the wave-per-channel-block kernel where it is built for the shape; DMF_PATCH_V1=1 forces the generic kernel (A/B runs)
-  static const bool force_v1 = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
-  if (!force_v1 && patch_v2_supported(*s, mode))
+  if (!force_v1() && patch_v2_supported(*s, mode))
     return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel (v2) launch");
   return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }

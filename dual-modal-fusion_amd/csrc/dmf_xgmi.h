@@ -9,8 +9,10 @@
 //   3. wait until flags[rank][region][peer][blk] >= seq for every peer         (relaxed polls, bounded by a wall-clock timeout)
 //   4. read the world values from the OWN inbox and add them in rank order
 // Reads only ever go to memory the reader allocated itself as uncached, so they can never be served from a stale cache
-// line: an IPC import does not carry the exporter's uncached attribute (a pull over the imported mapping was seen to
-// return a previous round's value once, with all ranks on one GPU).  Writes through the imported mapping are made
+// line.  An IPC import does not carry the exporter's uncached attribute: the first (pull) form of this exchange read the
+// peers' buffers through the imported mapping, those loads were cached in the READER's XCD L2, and the third round — the
+// first one to reuse a parity slot — summed the slot's round-1 content for every element (gpurun_out/dp3r.log of round 1:
+// all 1000 elements off by the known-answer pattern 3 * (i % 97)).  Writes through the imported mapping are made
 // visible by the system-scope release.  A peer can run at most one sequence number ahead (it needs this rank's flag to
 // finish the next one), which is what the two parities are for.  Blocks never wait for other blocks of the same grid.
 #pragma once
@@ -47,10 +49,12 @@ __device__ __forceinline__ float xgmi_exchange(const XgmiDev& x, int region, int
   }
   // Cache maintenance is the expensive part of any cross-agent handshake on this part (a device-scope release /
   // acquire pair costs ~10 us when every thread does it, tools/gridbar.hip), so it is done ONCE per block: the value
-  // stores above are write-through system-scope stores; the barrier below waits until every thread's stores have been
-  // acknowledged; thread 0 then issues one system-scope release and raises the flags with plain system-scope stores.
-  // Waiting polls with relaxed loads; the values are read from the reader's own UNCACHED inbox, so no acquire
-  // invalidation is needed on this side.
+  // stores above are write-through system-scope stores; EVERY storing wave waits for the acknowledgement of its own
+  // stores (s_waitcnt vmcnt(0): the workgroup barrier alone is a bare s_barrier on gfx950 and does not wait for them —
+  // without this wait the flag raised by wave 0 could overtake the data of waves 1..3); thread 0 then issues one
+  // system-scope release and raises the flags with plain system-scope stores.  Waiting polls with relaxed loads; the
+  // values are read from the reader's own UNCACHED inbox, so no acquire invalidation is needed on this side.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

@@ -70,12 +70,17 @@ class TrainEngine:
         self.host_cursor = 0
         self.graph = None
         self.graph_steps = 0
+        self.graph_hparams = None
 
     # ------------------------------------------------------------------ eager step (host-side step count)
-    def step(self, xy, labels):
+    def step(self, xy, labels, check=True):
         """One optimiser step on the patches at `xy` [B,2] int32 (device) with `labels` [B] int32 (device)."""
         if xy.shape[0] > self.B:
             raise lib.DmfError('engine was built for batches of at most %d, got %d' % (self.B, xy.shape[0]))
+        if check:     # one D2H copy per call; load_plan() validates a whole epoch at once and run_plan() skips this
+            lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy.cpu().numpy())
+            if labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= self.net.arch['K']):
+                raise lib.DmfError('label outside [0, %d)' % self.net.arch['K'])
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
         self._launch(inp, labels, None, None)
 
@@ -155,7 +160,9 @@ class TrainEngine:
         steps = self.plan_steps if steps is None else steps
         done = 0
         if steps_per_graph > 0 and (self.world == 1 or self.comm is not None):
-            if self.graph is None or self.graph_steps != steps_per_graph:
+            # lr, betas and eps are launch arguments baked into the captured graph (reference: `scheduler.step()` changes
+            # the optimiser's lr every epoch, mainsolver.py:60): a change invalidates the graph
+            if self.graph is None or self.graph_steps != steps_per_graph or self.graph_hparams != self._hparams():
                 self._capture(steps_per_graph)
             while steps - done >= steps_per_graph:
                 self._fill_window(steps_per_graph)
@@ -199,7 +206,10 @@ class TrainEngine:
                 inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.win_xy[k * self.B:(k + 1) * self.B])
                 self._launch(inp, self.win_lab[k * self.B:(k + 1) * self.B], self.dev_step, self.dev_cursor, self.loss_hist)
         self.step_count = count0
-        self.graph, self.graph_steps = g, n
+        self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
+
+    def _hparams(self):
+        return (self.lr, self.b1, self.b2, self.eps)
 
     def mean_losses(self):
         """Per-step mean CE of the plan steps run so far (one D2H copy)."""
@@ -270,7 +280,10 @@ class EvalEngine:
             from .parallel import shard_range
             lo, hi = shard_range(xy_all.shape[0], dist.get_rank(process_group), dist.get_world_size(process_group))
             xy_all = xy_all[lo:hi].contiguous()
-        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_all.cpu().numpy())
+        xy_host = xy_all.cpu().numpy()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy_host)
+        if len(xy_host) and (int(xy_host[:, 0].max()) >= H or int(xy_host[:, 1].max()) >= W):
+            raise lib.DmfError('pixel outside the %d x %d label map' % (H, W))      # labelmap_kernel writes map[x * W + y]
         if label_map is None:
             label_map = torch.zeros(H, W, dtype=torch.int32, device=dev)
         for i in range(0, xy_all.shape[0], self.B):
@@ -390,6 +403,13 @@ class QuaTrainEngine:
 
     def losses(self):
         return self.loss_hist[:int(self.dev_cursor.item())].cpu()
+
+    # bench.py: the step's dominant launch alone (for HIP-event timing) and its name
+    def time_dominant(self, inp):
+        lib.backward_dlogits(self.shape, inp, self.theta, self.net.pool_w, self.dlogits, self.ws)
+
+    def dominant_name(self):
+        return 'dmf::patch_kernel<ShapeQua, MODE_BWD> (dmf_backward_dlogits: forward recompute + backward of the 4*bs stacked patches)'
 
 
 class QuaEvalEngine:

@@ -46,6 +46,7 @@ def _load():
         'dmf_version': (i32, []),
         'dmf_last_error': (C.c_char_p, []),
         'dmf_shape_supported': (i32, [SP]),
+        'dmf_patch_variant': (i32, [SP, i32]),
         'dmf_param_layout': (i32, [SP, C.POINTER(i64)]),
         'dmf_workspace_bytes': (i64, [SP, i32]),
         'dmf_forward': (i32, [SP, IP, vp, vp, vp, vp, vp]),
@@ -100,6 +101,11 @@ def make_shape(arch):
 
 def shape_supported(shape):
     check(_lib.dmf_shape_supported(C.byref(shape)))
+
+
+def patch_v2_used(shape, mode=1):
+    """True if the train step (mode 1; 0 = forward, 2 = backward from dlogits) of this shape runs the v2 patch kernel."""
+    return _lib.dmf_patch_variant(C.byref(shape), mode) == 2
 
 
 def param_layout(shape):

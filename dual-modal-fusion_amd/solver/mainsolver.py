@@ -145,8 +145,22 @@ class Solver(BaseSolver):
             if xy.shape[0] != B:                                             # DataLoader keeps the short last batch
                 eng.step(xy.to(self.DEVICE), lab.to(self.DEVICE))
                 losses.append(float(eng.loss[:xy.shape[0]].mean().item()))
+        self._check_exchange()
         self.step_losses += losses
         return losses[-1] if losses else float('nan')
+
+    def _check_exchange(self):
+        """A timed-out wait of the one-shot gradient exchange leaves the ranks with different weights (the kernel sums what
+        it has and goes on).  Every rank learns of it here, once per epoch and before anything is saved: all ranks stop."""
+        if self.comm is None:
+            return
+        import torch.distributed as dist
+        bad = torch.tensor([int(self.comm.status())], dtype=torch.int32,
+                           device=self.DEVICE if dist.get_backend(self.process_group) == 'nccl' else 'cpu')
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.process_group)
+        if int(bad.item()) != 0:
+            raise RuntimeError('epoch %d: a gradient exchange timed out on at least one rank; the replicas have diverged. '
+                               'Restart from the last checkpoint with xgmi_exchange: 0 (RCCL all-reduce).' % self.epoch)
 
     def _train_epoch_dropin(self):
         loader = self._bar(self.train_loader)

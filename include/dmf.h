@@ -66,6 +66,11 @@ const char* dmf_last_error(void);
 /* 0 if a compiled kernel instance exists for this shape. */
 int32_t dmf_shape_supported(const dmf_shape* shape);
 
+/* Which patch kernel dmf_forward (mode 0), dmf_train_fwd_bwd (1) or dmf_backward_dlogits (2) launches for this shape:
+ * 2 = the wave-per-channel-segment kernel (csrc/dmf_patch_v2.hip), 1 = the generic kernel (csrc/dmf_patch_kernel.hip),
+ * 0 = no instance.  Reporting only (bench.py names the kernel it times); the arithmetic contract is the same. */
+int32_t dmf_patch_variant(const dmf_shape* shape, int32_t mode);
+
 /* Flat parameter vector theta (fp32).  Tensor order and offsets (in floats):
  *   0 spec_a.weight [F, C/G]   1 spec_a.bias [F]   2 spat_a.weight [F, 9]   3 spat_a.bias [F]
  *   4 lift_b.weight [F, C2*S*S] 5 lift_b.bias [F]  6 spat_b.weight [F, 9]   7 spat_b.bias [F]
