@@ -429,7 +429,7 @@ def main_stage2(args, dev):
     xy = np.stack([g.integers(0, H, total * bs), g.integers(0, W, total * bs)], 1).astype(np.int32)
     lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
     eng.load_plan(xy, lab)
-    spg = min(args.steps_per_graph, K_steps) if hasattr(eng, '_capture') else 0
+    spg = min(args.steps_per_graph, K_steps) if eng.unit else 0
     eng.run_plan(W_steps)
     launch, n_replays = launch_label(spg, K_steps)
     if n_replays:

@@ -214,6 +214,12 @@ __global__ __launch_bounds__(256) void pan2ms_kernel(const double* pan, int pitc
 
 using namespace dmf;
 
+// DMF_PATCH_V1=1 forces the generic patch kernel everywhere (A/B runs)
+static bool force_v1() {
+  static const bool f = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
+  return f;
+}
+
 extern "C" {
 
 int32_t dmf_version(void) { return DMF_VERSION; }
@@ -221,19 +227,15 @@ const char* dmf_last_error(void) { return g_err; }
 
 int32_t dmf_shape_supported(const dmf_shape* s) {
   if (s == nullptr) return fail("%s", "null shape");
-  if (!patch_shape_supported(*s)) {
-    snprintf(g_err, sizeof(g_err),
-             "no compiled kernel instance for C=%d C2=%d P=%d S=%d F=%d G=%d H=%d K=%d attention=%d "
-             "(instances: dmf_patch_kernel.hip, 'Compiled instances')",
-             s->C, s->C2, s->P, s->S, s->F, s->G, s->H, s->K, s->attention);
-    return 1;
-  }
-  return 0;
-}
-
-static bool force_v1() {
-  static const bool f = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
-  return f;
+  // the generic kernel's instances carry every mode (attention included); the v2 table adds late-fusion shapes
+  if (patch_shape_supported(*s)) return 0;
+  if (!s->attention && !force_v1() && patch_v2_supported(*s, MODE_TRAIN)) return 0;
+  snprintf(g_err, sizeof(g_err),
+           "no compiled kernel instance for C=%d C2=%d P=%d S=%d F=%d G=%d H=%d K=%d attention=%d; compiled (C/C2/P/S/F/G): "
+           "generic kernel 200/1/11/1/40/10 200/1/11/1/32/8 224/3/11/1/32/8 4/1/16/4/40/1 8/1/5/4/40/2 8/1/5/1/40/2 4/1/16/1/40/1 "
+           "4/1/5/1/40/1 (all modes, K <= 64); late fusion only:%s (subject to 160 KiB of LDS at this K)",
+           s->C, s->C2, s->P, s->S, s->F, s->G, s->H, s->K, s->attention, patch_v2_shape_list());
+  return 1;
 }
 
 int32_t dmf_patch_variant(const dmf_shape* s, int32_t mode) {
@@ -397,6 +399,55 @@ int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* 
   if (in != nullptr && in->B == 0) return 0;
   if (labels == nullptr || logits == nullptr || loss == nullptr) return fail("%s", "null labels/logits/loss");
   return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, adam_step_dev, stream);
+}
+
+int32_t dmf_unit_supported(const dmf_shape* s) {
+  if (s == nullptr) return fail("%s", "null shape");
+  if (force_v1() || s->attention || !patch_v2_supported(*s, MODE_UNIT))
+    return fail("no unit-gradient kernel for this shape (instances C/C2/P/S/F/G:%s)", patch_v2_shape_list());
+  return 0;
+}
+
+int32_t dmf_forward_unit(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w, float* logits,
+                         void* workspace, int32_t* adam_step_dev, void* stream) {
+  if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || logits == nullptr || workspace == nullptr)
+    return fail("%s", "null argument");
+  if (dmf_unit_supported(s)) return 1;
+  if (in->B < 0) return fail("%s", "negative batch");
+  if (in->B == 0) return 0;
+  if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");
+  if (in->mode == 1 && (in->sceneA == nullptr || in->sceneB == nullptr || in->xy == nullptr || in->Wp <= 0 || in->WpB <= 0))
+    return fail("%s", "mode 1 needs sceneA, sceneB, xy, Wp, WpB");
+  if (in->mode != 0 && in->mode != 1) return fail("%s", "input mode must be 0 or 1");
+  const Layout L = layout_of(*s);
+  const WsLayout w = make_ws(L, in->B);
+  float* ws = static_cast<float*>(workspace);
+  KArgs a{};
+  a.in = *in;
+  a.theta = theta;
+  a.pool = pool_w;
+  a.logits = logits;
+  a.adam_step = adam_step_dev;
+  a.K = s->K;
+  a.slab = ws + w.unit;          // MODE_UNIT: one row per patch
+  a.ws_z = ws + w.z;
+  a.ws_h = ws + w.h;
+  a.ws_dh = ws + w.dh;
+  a.ws_dl = ws + w.dl;
+  return check(patch_v2_dispatch(*s, MODE_UNIT, a, static_cast<hipStream_t>(stream)), "patch kernel (v2, unit) launch");
+}
+
+int32_t dmf_backward_unit(const dmf_shape* s, int32_t B, const float* theta, const float* dlogits, void* workspace,
+                          void* stream) {
+  if (s == nullptr || theta == nullptr || dlogits == nullptr || workspace == nullptr) return fail("%s", "null argument");
+  if (dmf_unit_supported(s)) return 1;
+  if (B < 0) return fail("%s", "negative batch");
+  if (B == 0) return 0;
+  const Layout L = layout_of(*s);
+  const WsLayout w = make_ws(L, B);
+  float* ws = static_cast<float*>(workspace);
+  UnitBwdArgs a{theta, dlogits, ws + w.unit, ws + w.h, ws + w.dh, ws + w.dl, ws + w.slab, B, s->K};
+  return check(patch_v2_unit_backward(*s, a, static_cast<hipStream_t>(stream)), "unit backward launch");
 }
 
 int32_t dmf_backward_dlogits(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,

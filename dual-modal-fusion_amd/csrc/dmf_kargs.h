@@ -9,9 +9,11 @@
 
 namespace dmf {
 
-enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4 };
+enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4, MODE_UNIT = 5 };
 // TOKENS: conv stages only, for the attention kernel.  DENSE: conv backward from dense dL/dYa, dL/dYb maps [B][F][P2]
 // (written by the attention kernel's backward) instead of the rank-1 pool x dz form; the head is skipped.
+// UNIT (v2 kernel only): forward + the conv backward for a UNIT gradient on every pooled feature; `slab` then is
+// [B][SLAB], one row of unit gradients per PATCH (dmf_forward_unit / dmf_backward_unit: a loss that couples the batch).
 
 // patch kernels (dmf_patch_kernel.hip, dmf_patch_v2.hip)
 struct KArgs {
@@ -42,6 +44,15 @@ hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStrea
 // wave-per-channel-block kernel (dmf_patch_v2.hip): FWD / TRAIN / BWD of the shapes it is built for
 int patch_v2_supported(const dmf_shape& s, int mode);
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
+// second half of the unit-gradient step: per patch dh, dz from dlogits; slab row of workgroup g = sum over its patches of
+// dz x unit row; ws_dh / ws_dl for the fc gradients
+struct UnitBwdArgs {
+  const float* theta; const float* dlogits; const float* unit; const float* ws_h;
+  float* ws_dh; float* ws_dl; float* slab;
+  int32_t B, K;
+};
+hipError_t patch_v2_unit_backward(const dmf_shape& s, const UnitBwdArgs& a, hipStream_t st);
+const char* patch_v2_shape_list();
 
 // attention kernels (dmf_attention.hip)
 struct AttnTrainArgs {

@@ -62,10 +62,10 @@ __device__ unsigned long long* g_v2stamps = nullptr;     // [block][16 waves][16
 
 typedef const int32_t __attribute__((address_space(4))) cint;
 
-// LDS-array cycles of one ds_read_b128 x-row read per wave, summed over the conv waves, for a pixel stride CS of the window
-// image [pixel][CS]: the 16 lanes of a service group hold different patch rows, and up to two band groups (a wave's channels
-// straddle groups).  Used to pick the stride's padding at compile time.
-constexpr int v2_read_cost(int CS, int P, int Cg, int lpc, int cpw, int M, int nb) {
+// LDS-array cycles of one ds_read_b128 x-row read per wave, summed over the conv waves, for a window image
+// [row][RS] = [row][P pixels x CS | row padding]: the 16 lanes of a service group hold different patch rows, and up to two
+// band groups (a wave's channels may straddle groups).  Used to pick the paddings at compile time.
+constexpr int v2_read_cost(int CS, int RS, int P, int Cg, int lpc, int cpw, int M, int nb) {
   const int first[4][3] = {{0, 12, 20}, {4, 16, 28}, {32, 44, 52}, {36, 48, 60}};
   const int count[4][3] = {{4, 4, 8}, {8, 4, 4}, {4, 4, 8}, {8, 4, 4}};
   int tot = 0;
@@ -80,7 +80,7 @@ constexpr int v2_read_cost(int CS, int P, int Cg, int lpc, int cpw, int M, int n
             const int seg = l / lpc, r = l % lpc;
             const int f = cpw * w + (seg < cpw ? seg : cpw - 1);
             const int rc = r < P ? r : P - 1;
-            const int addr = rc * P * CS + (f / M) * Cg;
+            const int addr = rc * RS + (f / M) * Cg;
             if (addr % 64 == b) {
               bool seen = false;
               for (int i = 0; i < n; ++i) seen = seen || addrs[i] == addr;
@@ -93,15 +93,20 @@ constexpr int v2_read_cost(int CS, int P, int Cg, int lpc, int cpw, int M, int n
     }
   return tot;
 }
-// smallest padding (0, 4 or 8 floats) within 30 % of conflict-free; more padding only where the unpadded stride is far off
-constexpr int v2_pick_cs(int C, int P, int Cg, int lpc, int cpw, int M, int nb) {
+// (pixel stride CS, row stride RS) packed as CS * 65536 + RS: the smallest image within 30 % of conflict-free reads — no
+// padding if that already holds, else row padding (keeps a window row one contiguous run of scene bytes), else pixel padding
+constexpr int v2_pick_layout(int C, int P, int Cg, int lpc, int cpw, int M, int nb) {
   const int ideal = 4 * nb;
-  for (int pad = 0; pad <= 8; pad += 4)
-    if (v2_read_cost(C + pad, P, Cg, lpc, cpw, M, nb) * 10 <= ideal * 13) return C + pad;
-  int best = C, bc = v2_read_cost(C, P, Cg, lpc, cpw, M, nb);
+  int best = C * 65536 + P * C, bc = v2_read_cost(C, P * C, P, Cg, lpc, cpw, M, nb);
+  if (bc * 10 <= ideal * 13) return best;
+  for (int rp = 4; rp <= 60; rp += 4) {
+    const int c = v2_read_cost(C, P * C + rp, P, Cg, lpc, cpw, M, nb);
+    if (c * 10 <= ideal * 13) return C * 65536 + P * C + rp;
+    if (c < bc) { bc = c; best = C * 65536 + P * C + rp; }
+  }
   for (int pad = 4; pad <= 32; pad += 4) {
-    const int c = v2_read_cost(C + pad, P, Cg, lpc, cpw, M, nb);
-    if (c < bc) { bc = c; best = C + pad; }
+    const int c = v2_read_cost(C + pad, P * (C + pad), P, Cg, lpc, cpw, M, nb);
+    if (c < bc) { bc = c; best = (C + pad) * 65536 + P * (C + pad); }
   }
   return best;
 }
@@ -115,17 +120,22 @@ constexpr int v2_pick_cpw(int F, int lpc) {
 template <class Sh, bool TR = true>
 struct V2 {
   static constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, G = Sh::G;
-  static constexpr int LPC = ((P + 1 + 3) / 4) * 4;   // lanes per channel: P rows + at least one zero-padding lane, whole quads
+  // lanes per channel: P rows + at least one zero-padding lane, whole quads — except P = 16, where a channel is exactly one
+  // 16-lane DPP row and the row shifts' own boundary zero-fill is the padding
+  static constexpr bool ROWDPP = (P == 16);
+  static constexpr int LPC = ROWDPP ? 16 : ((P + 1 + 3) / 4) * 4;
   static constexpr int CPW = v2_pick_cpw(F, LPC);     // channels per wave
   static constexpr int NQ = LPC / 4;                  // quad partials per channel sum
   static constexpr int NB = F / CPW;                  // conv wavefronts
   static constexpr int NW = NB + 1;                   // + the head wavefront
   static constexpr int NT = NW * 64;
-  // window in LDS: the patch image [P*P pixels][CS], pixel-major like the scene, so that a 1-KiB gather piece is (mostly)
-  // 1 KiB of contiguous scene bytes; CS = C + the padding that spreads the row-lanes' ds_read_b128 over the banks
+  // window in LDS: the patch image [P rows][RS] with RS = P pixels x CS (+ row padding), pixel-major like the scene, so that
+  // a 1-KiB gather piece is (mostly) 1 KiB of contiguous scene bytes; the paddings spread the row-lanes' ds_read_b128 over
+  // the banks (v2_pick_layout)
   static constexpr int QC = Cg / 4;
-  static constexpr int CS = v2_pick_cs(Sh::C, P, Cg, LPC, CPW, Sh::M, NB);
-  static constexpr int XF = ((P2 * CS + 255) / 256) * 256;   // floats, whole pieces
+  static constexpr int LAYOUT = v2_pick_layout(Sh::C, P, Cg, LPC, CPW, Sh::M, NB);
+  static constexpr int CS = LAYOUT / 65536, RS = LAYOUT % 65536;
+  static constexpr int XF = ((P * RS + 255) / 256) * 256;    // floats, whole pieces
   static constexpr int NPIECE = XF / 256;
   static constexpr int NK = (NPIECE + NW - 1) / NW;   // pieces per wave (all NW waves gather)
   static constexpr int AR0 = P * C2;                  // aux floats per patch row
@@ -149,8 +159,8 @@ struct V2 {
   static constexpr int oW2 = oSlab + NCOPY * Sh::SLAB;   // fc2.weight [K rounded up to 4][W2S]  (run-time K)
   static constexpr int FIXED = oW2;
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
-  static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
-                             Sh::SLAB / 4 <= NT && P * RSP <= NT && NK <= 16;
+  static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && P <= 16 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
+                             P * RSP <= 2 * NT && NK <= 16;
 };
 
 // LDS reads the compiler's waitcnt pass cannot see.  It orders EVERY LDS access it knows of behind all outstanding
@@ -191,11 +201,17 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ float relu_lim(float x, float lim) { return __builtin_amdgcn_fmed3f(x, 0.f, lim); }   // lim = +inf: ReLU; 0: 0
 
-__device__ __forceinline__ float lane_above(float v) {   // value held by lane-1 (patch row r-1, or the previous channel's padding lane); 0 at lane 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));   // wave_shr:1
+// value held by lane-1 / lane+1 = patch row r-1 / r+1 (or a padding lane).  ROWDPP (16-row patches, one channel per 16-lane
+// DPP row): row shifts, which fill with zero at the row's ends; otherwise whole-wave shifts (zero at lanes 0 / 63).
+template <bool ROWDPP>
+__device__ __forceinline__ float lane_above(float v) {
+  if constexpr (ROWDPP) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));   // row_shr:1
+  else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));                    // wave_shr:1
 }
-__device__ __forceinline__ float lane_below(float v) {   // lane+1 (patch row r+1, or this channel's padding lane); 0 at lane 63
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));   // wave_shl:1
+template <bool ROWDPP>
+__device__ __forceinline__ float lane_below(float v) {
+  if constexpr (ROWDPP) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));   // row_shl:1
+  else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));                    // wave_shl:1
 }
 __device__ __forceinline__ float quad_sum(float v) {     // over the 4 lanes of a quad, result in each of them
   v = DMF_DPP_ADD(v, 0xB1);     // quad_perm [1,0,3,2]
@@ -211,11 +227,11 @@ __device__ __forceinline__ float quad_sum(float v) {     // over the 4 lanes of 
 template <int P>
 struct ConvRows { float y1u[P], y1d[P], gq[P]; };
 
-template <int P>
+template <int P, bool RD>
 __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
                                              ConvRows<P>& t, float& z) {
 #pragma unroll
-  for (int c = 0; c < P; ++c) { t.y1u[c] = lane_above(y1c[c]); t.y1d[c] = lane_below(y1c[c]); }
+  for (int c = 0; c < P; ++c) { t.y1u[c] = lane_above<RD>(y1c[c]); t.y1d[c] = lane_below<RD>(y1c[c]); }
   z = 0.f;
 #pragma unroll
   for (int c = 0; c < P; ++c) {
@@ -234,7 +250,7 @@ __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float 
   }
 }
 
-template <int P>
+template <int P, bool RD>
 __device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float (&w)[9], const ConvRows<P>& t,
                                              float (&dw)[9], float& db, float (&dy)[P]) {
 #pragma unroll
@@ -256,7 +272,7 @@ __device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float 
   // dY1(r,c) = [y1 > 0] * sum_{u,v} W[u][v] * dY2(r-u+1, c-v+1): u = 0 pairs with the row below, u = 2 with the row above
   float gu[P], gd[P];
 #pragma unroll
-  for (int c = 0; c < P; ++c) { gu[c] = lane_above(t.gq[c]); gd[c] = lane_below(t.gq[c]); }
+  for (int c = 0; c < P; ++c) { gu[c] = lane_above<RD>(t.gq[c]); gd[c] = lane_below<RD>(t.gq[c]); }
 #pragma unroll
   for (int c = 0; c < P; ++c) {
     float s = 0.f;
@@ -273,12 +289,12 @@ __device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float 
   }
 }
 
-template <int P, bool TR>
+template <int P, bool TR, bool RD>
 __device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
                                          float& z, float (&dw)[9], float& db, float (&dy)[P]) {
   ConvRows<P> t;
-  conv_row_fwd<P>(y1c, w, bias, pw, t, z);
-  if constexpr (TR) conv_row_bwd<P>(y1c, w, t, dw, db, dy);
+  conv_row_fwd<P, RD>(y1c, w, bias, pw, t, z);
+  if constexpr (TR) conv_row_bwd<P, RD>(y1c, w, t, dw, db, dy);
 }
 
 // One piece of LDS-DMA: lane l reads BYTES (4 or 16) bytes at base + soff + voff into lds + BYTES l (lanes with voff < 0 are
@@ -301,6 +317,7 @@ __device__ __forceinline__ void gather_piece(const float* base, int soff, int vo
 template <class Sh, int MODE, int INMODE>
 __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   constexpr bool TR = (MODE != MODE_FWD);
+  constexpr bool UNIT = (MODE == MODE_UNIT);           // forward + unit gradients per patch; loss and scaling happen elsewhere
   using V = V2<Sh, TR>;
   constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, QC = V::QC;
   constexpr int LPC = V::LPC, CPW = V::CPW, NQ = V::NQ;
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   if (wave == V::NB) __builtin_amdgcn_s_setprio(3);
   else if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
                                                           // wave of a SIMD wins every arbitration and the younger one trails it
-  if (MODE == MODE_TRAIN && a.adam_step != nullptr && blockIdx.x == 0 && tid == 0) *a.adam_step += 1;
+  if ((MODE == MODE_TRAIN || UNIT) && a.adam_step != nullptr && blockIdx.x == 0 && tid == 0) *a.adam_step += 1;
   const int boff = (a.in.cursor != nullptr) ? ((cint*)a.in.cursor)[0] * B : 0;     // epoch-plan offset of this batch
   // first patch's coordinates: requested before anything else (kernarg -> coordinates -> gather is the kernel's longest
   // dependent chain of memory round trips; the table staging below runs under it)
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     xn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + blockIdx.x) + 1];
   }
   if constexpr (TR) {   // the slab rows' padding beyond the last parameter is copied out too: keep it zero
-    if (tid < Sh::SLAB - Sh::NCONV) {
+    if (tid < Sh::SLAB - Sh::NCONV) {                   // (< 32 elements)
 #pragma unroll
       for (int c = 0; c < V::NCOPY; ++c) sSlab[c * Sh::SLAB + Sh::NCONV + tid] = 0.f;
     }
@@ -370,15 +387,15 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       const int p = wave + k * V::NW;
       const int n = 256 * p + 4 * lane;
       int off;
-      if constexpr (V::CS == Sh::C) {                        // unpadded image: window rows are contiguous runs of the scene
-        const int pr = n / (P * Sh::C);
-        off = (n + pr * rowskip) * 4;
-        if (n >= P2 * Sh::C) off = -1;
+      if constexpr (V::CS == Sh::C) {                        // unpadded pixels: a window row is one contiguous run of the scene
+        const int pr = n / V::RS, within = n - pr * V::RS;
+        off = (within + pr * (rowskip + P * Sh::C)) * 4;
+        if (pr >= P || within >= P * Sh::C) off = -1;
       } else {
-        const int pix = n / V::CS, band = n - pix * V::CS;
-        const int pr = pix / P;
-        off = (pix * Sh::C + band + pr * rowskip) * 4;
-        if (pix >= P2 || band >= Sh::C) off = -1;
+        const int pr = n / V::RS, within = n - pr * V::RS;
+        const int pc = within / V::CS, band = within - pc * V::CS;
+        off = ((pr * a.in.Wp + pc) * Sh::C + band) * 4;
+        if (pr >= P || pc >= P || band >= Sh::C) off = -1;
       }
       if (p >= V::NPIECE) off = -1;
       gather_piece(base, 0, off, smem + V::oX + (p < V::NPIECE ? p : 0) * 256);
@@ -388,27 +405,49 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   // Behind barrier 2, all waves: dL/dz[i] = sum_j fc1.weight[j][i] dh[j] (4 lanes per i), then the workgroup's slab row =
   // sum of the quad copies of the UNIT gradients x dL/dz of each element's channel, in one coalesced pass (streaming stores:
   // next read by the reduce kernel).  A workgroup that walks several patches accumulates in its (L2-resident) global row.
-  int dzix = 0;                                            // channel (dz index) of each of this thread's 4 slab elements, 8 bits each
+  constexpr int NI = (Sh::SLAB / 4 + V::NT - 1) / V::NT;   // 16-byte slab pieces per thread
+  int dzix[NI];                                            // channel (dz index) of each of this thread's slab elements, 8 bits each
   if constexpr (TR) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int p = 4 * tid + e;
-      int ix = 0;
-      if (p < Sh::oA1b) ix = p / Cg;
-      else if (p < Sh::oA2w) ix = p - Sh::oA1b;
-      else if (p < Sh::oA2b) ix = (p - Sh::oA2w) / 9;
-      else if (p < Sh::oB1w) ix = p - Sh::oA2b;
-      else if (p < Sh::oB1b) ix = F + (p - Sh::oB1w) / Sh::TB;
-      else if (p < Sh::oB2w) ix = F + p - Sh::oB1b;
-      else if (p < Sh::oB2b) ix = F + (p - Sh::oB2w) / 9;
-      else if (p < Sh::NCONV) ix = F + p - Sh::oB2b;
-      dzix |= ix << (8 * e);
+    for (int i = 0; i < NI; ++i) {
+      dzix[i] = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = 4 * (tid + i * V::NT) + e;
+        int ix = 0;
+        if (p < Sh::oA1b) ix = p / Cg;
+        else if (p < Sh::oA2w) ix = p - Sh::oA1b;
+        else if (p < Sh::oA2b) ix = (p - Sh::oA2w) / 9;
+        else if (p < Sh::oB1w) ix = p - Sh::oA2b;
+        else if (p < Sh::oB1b) ix = F + (p - Sh::oB1w) / Sh::TB;
+        else if (p < Sh::oB2w) ix = F + p - Sh::oB1b;
+        else if (p < Sh::oB2b) ix = F + (p - Sh::oB2w) / 9;
+        else if (p < Sh::NCONV) ix = F + p - Sh::oB2b;
+        dzix[i] |= ix << (8 * e);
+      }
     }
   }
-  auto scale_and_store = [&](int it) {
+  auto scale_and_store = [&](int it, int b) {
+    if constexpr (UNIT) {   // the patch's unit gradients (sum of the quad copies), unscaled, to its own row
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int t = tid + i * V::NT;
+        if (t < Sh::SLAB / 4) {
+          float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * t);
+#pragma unroll
+          for (int c = 1; c < V::NCOPY; ++c) {
+            const float4 u = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * t);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          }
+          *reinterpret_cast<float4*>(a.slab + (size_t)b * Sh::SLAB + 4 * t) = v;
+        }
+      }
+      LDS_BARRIER();                                     // the copies are rewritten by the next patch
+      return;
+    }
     float* sDz = smem + V::oDz;
-    if (tid < 4 * F2) {
-      const int i = tid >> 2, m = tid & 3;
+    for (int t = tid; t < 4 * F2; t += V::NT) {          // (whole quads: NT and 4 F2 are multiples of 4)
+      const int i = t >> 2, m = t & 3;
       float d = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -420,26 +459,32 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       if (m == 0) sDz[i] = d;
     }
     LDS_BARRIER();                                       // barrier 3: dz complete
-    if (tid < Sh::SLAB / 4) {
-      float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * tid);
 #pragma unroll
-      for (int c = 1; c < V::NCOPY; ++c) {
-        const float4 t = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * tid);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    for (int i = 0; i < NI; ++i) {
+      const int t = tid + i * V::NT;
+      if (t < Sh::SLAB / 4) {
+        float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * t);
+#pragma unroll
+        for (int c = 1; c < V::NCOPY; ++c) {
+          const float4 u = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * t);
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const int dx = dzix[i];
+        v.x *= sDz[dx & 255]; v.y *= sDz[(dx >> 8) & 255]; v.z *= sDz[(dx >> 16) & 255]; v.w *= sDz[(dx >> 24) & 255];
+        float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB + 4 * t;
+        if (it > 0) {
+          const float4 o = *reinterpret_cast<const float4*>(slab);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        __builtin_nontemporal_store(v.x, slab);
+        __builtin_nontemporal_store(v.y, slab + 1);
+        __builtin_nontemporal_store(v.z, slab + 2);
+        __builtin_nontemporal_store(v.w, slab + 3);
       }
-      v.x *= sDz[dzix & 255]; v.y *= sDz[(dzix >> 8) & 255]; v.z *= sDz[(dzix >> 16) & 255]; v.w *= sDz[(dzix >> 24) & 255];
-      float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB + 4 * tid;
-      if (it > 0) {
-        const float4 o = *reinterpret_cast<const float4*>(slab);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      __builtin_nontemporal_store(v.x, slab);
-      __builtin_nontemporal_store(v.y, slab + 1);
-      __builtin_nontemporal_store(v.z, slab + 2);
-      __builtin_nontemporal_store(v.w, slab + 3);
     }
+    if (gridDim.x < (unsigned)B) LDS_BARRIER();          // more patches follow: the copies are rewritten by the next one
   };
-  static_assert(!TR || (4 * F2 <= V::NT && F2 <= 255), "dz mapping");
+  static_assert(F2 <= 255, "dz index in 8 bits");
 
   if (wave < V::NB) {
     // =============================================================================== conv wavefronts
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     const int qd = r >> 2;                                                         \
     const bool lead = vch && (r & 3) == 0;                                         \
     const float lim = act ? INFINITY : 0.f;                                        \
-    const float* xr = smem + V::oX + rc * P * V::CS + (f / Sh::M) * Cg;             \
+    const float* xr = smem + V::oX + rc * V::RS + (f / Sh::M) * Cg;                 \
     float* sl = sSlab + qd * Sh::SLAB;                                             \
     (void)lead; (void)lim; (void)xr; (void)sl; (void)qd; (void)act
     VSTAMP(1);
@@ -506,7 +551,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         const float* __restrict__ srcA = a.in.a + (size_t)(boff + b) * Sh::C * P2;
         for (int e = tid; e < Sh::C * P2; e += V::NB * 64) {
           const int cb = e / P2, pix = e - cb * P2;
-          smem[V::oX + pix * V::CS + cb] = srcA[e];
+          smem[V::oX + (pix / P) * V::RS + (pix % P) * V::CS + cb] = srcA[e];
         }
       }
       VSTAMP(2);
@@ -541,7 +586,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           for (int k = 0; k < C2; ++k) v = fmaf(wl[k], ax[c * C2 + k], v);
           y1b[c] = relu_lim(v, lim);
         }
-        conv_row<P, TR>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb);
+        conv_row<P, TR, V::ROWDPP>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb);
         zb = quad_sum(zb);
         if constexpr (TR) {
 #pragma unroll
@@ -619,7 +664,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       }
       float za, dwa[9], dba = 0.f, dya[P];
       ConvRows<P> ta;
-      conv_row_fwd<P>(y1a, w2a, act ? b2a : -1e30f, pw, ta, za);
+      conv_row_fwd<P, V::ROWDPP>(y1a, w2a, act ? b2a : -1e30f, pw, ta, za);
       za = quad_sum(za);
       {   // pooled features of the wave's channels: quad partials -> wave-private scratch -> one lane per value sums NQ of them
         float* zp = smem + V::oZP + wave * V::ZPW;
@@ -641,7 +686,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       // spat_a's unit backward runs BEHIND barrier 1: the head starts a conv backward earlier, and its chain of LDS round
       // trips (fc1 -> fc2 -> softmax -> dh) begins while the conv waves execute pure vector work instead of queueing behind
       // their window reads
-      conv_row_bwd<P>(y1a, w2a, ta, dwa, dba, dya);
+      conv_row_bwd<P, V::ROWDPP>(y1a, w2a, ta, dwa, dba, dya);
 
       // ------------------------------------------------------------------ unit gradients of spec_a from the still-resident window
       float acc[Cg], db1 = 0.f;
@@ -683,7 +728,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       VSTAMP(7);
       LDS_BARRIER();                                     // barrier 2: dh and the unit gradients complete
       VSTAMP(8);
-      scale_and_store(it);
+      scale_and_store(it, b);
       VSTAMP(9);
     }
   } else {
@@ -735,7 +780,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
             if (i0 + u < K4 / 4) *reinterpret_cast<float4*>(sW2 + k * V::W2S + 4 * c4) = v[u];
           }
         }
-        if constexpr (TR) {
+        if constexpr (TR && !UNIT) {
 #pragma unroll
           for (int q = 0; q < F2 / 4; ++q) {
             sW1T[(4 * q) * H + lane] = w1r[q].x;
@@ -787,7 +832,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       const unsigned long long bal = __ballot(lg == mx);
       const int pred_b = __ffsll((long long)bal) - 1;              // first maximal index, as torch.max
       float loss_b = 0.f, dl = 0.f, dh = 0.f;
-      if constexpr (TR) {
+      if constexpr (TR && !UNIT) {
         if (MODE == MODE_TRAIN) {
           const float e = lane < K ? __expf(lg - mx) : 0.f;
           const float se = wave_sum_dpp(e);
@@ -819,15 +864,17 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       VSTAMP(7);
       if constexpr (TR) LDS_BARRIER();                   // barrier 2: dh and the unit gradients complete
       VSTAMP(8);
-      if constexpr (TR) scale_and_store(it);
+      if constexpr (TR) scale_and_store(it, b);
       // this patch's head vectors for the gradient reduce
       if ((MODE != MODE_BWD || a.logits != nullptr) && lane < K) a.logits[(size_t)b * K + lane] = lg;
       if (a.pred != nullptr && lane == 0) a.pred[b] = pred_b;
       if constexpr (TR) {
         if (MODE == MODE_TRAIN && lane == 0) a.loss[b] = loss_b;
         a.ws_h[(size_t)b * H + lane] = h;
-        a.ws_dh[(size_t)b * H + lane] = dh;
-        a.ws_dl[(size_t)b * KMAX + lane] = dl;
+        if constexpr (!UNIT) {
+          a.ws_dh[(size_t)b * H + lane] = dh;
+          a.ws_dl[(size_t)b * KMAX + lane] = dl;
+        }
         if (lane < F2) a.ws_z[(size_t)b * F2 + lane] = zo0;
         if (F2 > 64 && 64 + lane < F2) a.ws_z[(size_t)b * F2 + 64 + lane] = zo1;
       }
@@ -837,6 +884,84 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   VSTAMP_W(10);
   VSTAMP_RT(13);
   VSTAMP_DUMP();
+}
+
+// ---------------------------------------------------------------------------------------- unit-gradient step, second half
+// For a loss that couples the whole batch (qua_loss, train/loss_function.py:15-76) the patch kernel cannot form dL/dlogits
+// itself.  MODE_UNIT leaves, per patch, the head vectors and one row of UNIT conv gradients; once the loss kernel has
+// produced dL/dlogits this kernel finishes the backward WITHOUT touching the patches again:
+//   dh = relu'(h) * W2^T dl,   dz = W1^T dh,   slab row of workgroup g = sum over its patches of dz[channel(p)] * unit[b][p]
+// (exact: the net is piecewise linear and channel f reaches the head only through z_a[f], z_b[f]).  ws_dh / ws_dl feed the
+// fc gradients of the reduce kernel as usual.
+template <class Sh>
+__global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a) {
+  constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, Cg = Sh::Cg;
+  constexpr int W1S = F2 + 1;                       // column reads of fc1.weight: odd stride
+  constexpr int NE = (Sh::SLAB + 255) / 256;        // slab elements per thread
+  __shared__ float sW1[H * W1S];
+  __shared__ float sW2[KMAX * (H + 1)];
+  __shared__ float sDl[KMAX], sDh[H], sDz[F2 + 1];
+  const int tid = threadIdx.x, K = a.K;
+  for (int i = tid; i < H * F2; i += 256) sW1[(i / F2) * W1S + (i % F2)] = a.theta[Sh::oFc1w + i];
+  for (int i = tid; i < K * H; i += 256) sW2[(i / H) * (H + 1) + (i % H)] = a.theta[Sh::oFc2w + i];
+  int ix[NE];                                       // dz index of this thread's slab elements
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int p = tid + 256 * e;
+    int v = F2;                                     // padding: multiplies with sDz[F2] = 0
+    if (p < Sh::oA1b) v = p / Cg;
+    else if (p < Sh::oA2w) v = p - Sh::oA1b;
+    else if (p < Sh::oA2b) v = (p - Sh::oA2w) / 9;
+    else if (p < Sh::oB1w) v = p - Sh::oA2b;
+    else if (p < Sh::oB1b) v = F + (p - Sh::oB1w) / Sh::TB;
+    else if (p < Sh::oB2w) v = F + p - Sh::oB1b;
+    else if (p < Sh::oB2b) v = F + (p - Sh::oB2w) / 9;
+    else if (p < Sh::NCONV) v = F + p - Sh::oB2b;
+    ix[e] = v;
+  }
+  float acc[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) acc[e] = 0.f;
+  if (tid == 0) sDz[F2] = 0.f;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    float u[NE];                                    // this patch's unit row: issued before the head math
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int p = tid + 256 * e;
+      u[e] = p < Sh::SLAB ? a.unit[(size_t)b * Sh::SLAB + p] : 0.f;
+    }
+    float hj = 0.f;
+    if (tid < KMAX) {
+      const float d = tid < K ? a.dlogits[(size_t)b * K + tid] : 0.f;
+      sDl[tid] = d;
+      a.ws_dl[(size_t)b * KMAX + tid] = d;
+    }
+    if (tid < H) hj = a.ws_h[(size_t)b * H + tid];
+    __syncthreads();
+    if (tid < H) {
+      float s = 0.f;
+      for (int k = 0; k < K; ++k) s = fmaf(sW2[k * (H + 1) + tid], sDl[k], s);
+      const float dh = hj > 0.f ? s : 0.f;
+      sDh[tid] = dh;
+      a.ws_dh[(size_t)b * H + tid] = dh;
+    }
+    __syncthreads();
+    if (tid < F2) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < H; ++j) s = fmaf(sW1[j * W1S + tid], sDh[j], s);
+      sDz[tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = fmaf(sDz[ix[e]], u[e], acc[e]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int p = tid + 256 * e;
+    if (p < Sh::SLAB) a.slab[(size_t)blockIdx.x * Sh::SLAB + p] = acc[e];
+  }
 }
 
 // ---------------------------------------------------------------------------------------- launch
@@ -867,16 +992,28 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
       return gather ? launch_v2_inst<Sh, MODE_TRAIN, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_TRAIN, 0>(a, grid, bytes, st);
     case MODE_BWD:
       return gather ? launch_v2_inst<Sh, MODE_BWD, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_BWD, 0>(a, grid, bytes, st);
+    case MODE_UNIT:
+      return gather ? launch_v2_inst<Sh, MODE_UNIT, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_UNIT, 0>(a, grid, bytes, st);
     default:
       return hipErrorInvalidValue;
   }
 }
 
-// Compiled instances.  (C, C2, P, S, F, G, H)
-using V2HSI = Shape<200, 1, 11, 1, 40, 10, 64>;      // BASELINE configs 1-2
-using V2HSI224 = Shape<224, 3, 11, 1, 32, 8, 64>;    // BASELINE config 4
-using V2Tiny1 = Shape<8, 1, 5, 1, 40, 2, 64>;        // small test scene, equal resolution
-using V2QuaTiny = Shape<4, 1, 5, 1, 40, 1, 64>;
+// Compiled instances: ONE table.  X(C, C2, P, S, F, G, H) — every row gets forward / train / backward-from-dlogits /
+// unit-gradient kernels for both input modes, the unit backward kernel, and its line in the supported-shape listing.
+// A row must satisfy V2<>::OK (S = 1, whole 16-byte band chunks per group, <= 12 waves) and fit 160 KiB of LDS at the
+// run-time K (v2_fits): 13x13 patches of a 200-band scene do not (the window alone is 135 KB) — no instance can exist
+// for them on this design; 224 bands at gmf.width 40 have no group count that divides both (G | gcd(224, 40) = 8 gives
+// 5 channels per group, but a group's bands must be whole 16-byte chunks shared by 4-channel multiples: M % 4 == 0).
+#define DMF_V2_SHAPES(X)                                                                                      \
+  X(200, 1, 11, 1, 40, 10, 64) /* BASELINE configs 1-2 */                                                     \
+  X(200, 1, 9, 1, 40, 10, 64)                                                                                 \
+  X(200, 1, 7, 1, 40, 10, 64)                                                                                 \
+  X(224, 3, 11, 1, 32, 8, 64)  /* BASELINE config 3 */                                                        \
+  X(224, 3, 9, 1, 32, 8, 64)                                                                                  \
+  X(8, 1, 5, 1, 40, 2, 64)     /* small test scene, equal resolution */                                       \
+  X(4, 1, 16, 1, 40, 1, 64)    /* stage 2 of the two-stage path: one 4-band stream + its band mean */          \
+  X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */
 
 template <class Sh>
 static bool v2_matches(const dmf_shape& s) {
@@ -888,16 +1025,42 @@ template <class Sh>
 static bool v2_fits(const dmf_shape& s) { return v2_matches<Sh>(s) && V2<Sh, true>::lds_bytes(s.K) <= 160 * 1024; }
 
 int patch_v2_supported(const dmf_shape& s, int mode) {
-  if (mode != MODE_FWD && mode != MODE_TRAIN && mode != MODE_BWD) return 0;
+  if (mode != MODE_FWD && mode != MODE_TRAIN && mode != MODE_BWD && mode != MODE_UNIT) return 0;
   if (s.K < 1 || s.K > KMAX || s.attention) return 0;
-  return v2_fits<V2HSI>(s) || v2_fits<V2HSI224>(s) || v2_fits<V2Tiny1>(s) || v2_fits<V2QuaTiny>(s);
+#define X(C, C2, P, S, F, G, H) if (v2_fits<Shape<C, C2, P, S, F, G, H>>(s)) return 1;
+  DMF_V2_SHAPES(X)
+#undef X
+  return 0;
+}
+
+// "C/C2/P/S/F/G" of every row, for error messages
+const char* patch_v2_shape_list() {
+#define STR2(x) #x
+#define STR(x) STR2(x)
+#define X(C, C2, P, S, F, G, H) " " STR(C) "/" STR(C2) "/" STR(P) "/" STR(S) "/" STR(F) "/" STR(G)
+  return DMF_V2_SHAPES(X);
+#undef X
+#undef STR
+#undef STR2
 }
 
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
-  if (v2_matches<V2HSI>(s)) return launch_v2<V2HSI>(mode, a, st);
-  if (v2_matches<V2HSI224>(s)) return launch_v2<V2HSI224>(mode, a, st);
-  if (v2_matches<V2Tiny1>(s)) return launch_v2<V2Tiny1>(mode, a, st);
-  if (v2_matches<V2QuaTiny>(s)) return launch_v2<V2QuaTiny>(mode, a, st);
+#define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2<Shape<C, C2, P, S, F, G, H>>(mode, a, st);
+  DMF_V2_SHAPES(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+hipError_t patch_v2_unit_backward(const dmf_shape& s, const UnitBwdArgs& a, hipStream_t st) {
+  const int grid = a.B < MAX_BLOCKS ? a.B : MAX_BLOCKS;
+  if (grid <= 0) return hipSuccess;
+#define X(C, C2, P, S, F, G, H)                                                                              \
+  if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) {                                                          \
+    hipLaunchKernelGGL((unit_backward_kernel<Shape<C, C2, P, S, F, G, H>>), dim3(grid), dim3(256), 0, st, a); \
+    return hipGetLastError();                                                                                \
+  }
+  DMF_V2_SHAPES(X)
+#undef X
   return hipErrorInvalidValue;
 }
 

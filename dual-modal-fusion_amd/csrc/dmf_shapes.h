@@ -79,7 +79,8 @@ inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int 
 
 // workspace layout (floats): [slab MAX_BLOCKS x SLAB][z B x 2F][h B x H][dh B x H][dl B x KMAX]
 //                            [attention: aslab MAX_BLOCKS x 4EF — per-workgroup gradients of Wq, Wk, Wv, Wo]
-struct WsLayout { int64_t slab, z, h, dh, dl, aslab, total; };
+//                            [unit B x SLAB — per-PATCH unit conv gradients of the two-launch step (dmf_forward_unit)]
+struct WsLayout { int64_t slab, z, h, dh, dl, aslab, unit, total; };
 inline WsLayout make_ws(const Layout& L, int B) {
   WsLayout w{};
   int64_t o = 0;
@@ -89,6 +90,7 @@ inline WsLayout make_ws(const Layout& L, int B) {
   w.dh = o;   o += (int64_t)B * L.H;
   w.dl = o;   o += (int64_t)B * KMAX;
   w.aslab = o; o += L.attention ? (int64_t)MAX_BLOCKS * 4 * L.E * L.F : 0;
+  w.unit = o;  o += L.attention ? 0 : (int64_t)B * L.SLAB;
   w.total = o;
   return w;
 }

@@ -328,43 +328,107 @@ class QuaScene:
 
 
 class QuaTrainEngine:
-    """Stage-2 train step (tostagesolver.py:268-278) on the resident tall scene: forward of the 4*bs stacked patches,
-    `dmf_qua_loss` (value + d/dlogits), `dmf_backward_dlogits`, `dmf_grad_reduce_adam` — four launches, no host sync.
-    The loss couples the whole batch, so it cannot ride inside the per-patch kernel like cross-entropy does."""
+    """Stage-2 train step (tostagesolver.py:268-278) on the resident tall scene, no host sync.  The loss couples the whole
+    batch, so it cannot ride inside the per-patch kernel like cross-entropy does.  Two forms:
+      * unit-gradient step (shapes with a v2 kernel): `dmf_forward_unit` (forward of the 4*bs stacked patches + the conv
+        backward for a unit gradient per pooled feature) -> `dmf_qua_loss` (value + d/dlogits) -> `dmf_backward_unit`
+        (dh, dz, scaled slab rows) -> `dmf_grad_reduce_adam`: the patches are visited ONCE, and the four launches replay
+        from a captured hipGraph (`run_plan(steps, steps_per_graph)`);
+      * otherwise `dmf_forward` -> `dmf_qua_loss` -> `dmf_backward_dlogits` (recomputes the forward) -> reduce + ADAM.
+    Data parallel (process_group): every rank takes its shard of each batch; the logits of all ranks are gathered so that
+    the batch-coupled loss is the GLOBAL batch's, the flat gradient is all-reduced (sum) and ADAM runs with 1/world."""
 
-    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
         if not net.arch.get('single_input'):
             raise lib.DmfError('stage 2 needs the single-input net (cfg["gmf"]["single_input"] = 1)')
         self.net, self.scene, self.bs = net, scene, int(bs)
         self.shape = net.shape
         lib.shape_supported(self.shape)
+        self.unit = lib.unit_supported(self.shape)
         self.params = lib.qua_params(dqtl)
         self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         dev = scene.device
         self.theta = net.flat_parameters()
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
+        self.grad = torch.zeros_like(self.theta)
         K = net.arch['K']
+        self.pg, self.world, self.rank = process_group, 1, 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
         self.logits = torch.empty(4 * self.bs, K, device=dev)
         self.dlogits = torch.empty(4 * self.bs, K, device=dev)
         self.loss = torch.zeros(1, device=dev)
         self.ws = torch.empty(lib.workspace_bytes(self.shape, 4 * self.bs) // 4, device=dev)
         self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.step_count = 0
-        self.plan_xy = self.plan_labels = self.loss_hist = None
+        self.plan_xy = self.plan_labels = self.plan_labels_global = self.loss_hist = None
+        self.graph, self.graph_steps, self.graph_hparams = None, 0, None
 
-    def _step(self, inp, bs, labels, cursor, loss_hist):
+    def _hparams(self):
+        return (self.lr, self.b1, self.b2, self.eps)
+
+    def _step(self, inp, bs, labels, cursor, loss_hist, dev_step=None):
         self.step_count += 1
         theta = self.theta
-        lib.forward(self.shape, inp, theta, self.net.pool_w, self.logits)
-        lib.qua_loss(self.logits[:4 * bs], bs, labels, self.params, loss=self.loss, dlogits=self.dlogits[:4 * bs],
-                     cursor=cursor, loss_hist=loss_hist)
-        lib.backward_dlogits(self.shape, inp, theta, self.net.pool_w, self.dlogits, self.ws)
-        lib.grad_reduce_adam(self.shape, 4 * bs, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
-                             self.step_count, cursor_dev=cursor)
+        if self.unit:
+            lib.forward_unit(self.shape, inp, theta, self.net.pool_w, self.logits, self.ws, adam_step_dev=dev_step)
+        else:
+            lib.forward(self.shape, inp, theta, self.net.pool_w, self.logits)
+        if self.world == 1:
+            lib.qua_loss(self.logits[:4 * bs], bs, labels, self.params, loss=self.loss, dlogits=self.dlogits[:4 * bs],
+                         cursor=cursor, loss_hist=loss_hist)
+        else:
+            self._global_loss(bs, labels, cursor, loss_hist)
+        if self.unit:
+            lib.backward_unit(self.shape, 4 * bs, theta, self.dlogits, self.ws)
+        else:
+            lib.backward_dlogits(self.shape, inp, theta, self.net.pool_w, self.dlogits, self.ws)
+        if self.world == 1:
+            lib.grad_reduce_adam(self.shape, 4 * bs, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
+                                 self.step_count, adam_step_dev=dev_step if self.unit else None, cursor_dev=cursor)
+        else:
+            import torch.distributed as dist
+            lib.grad_reduce(self.shape, 4 * bs, self.ws, self.grad)
+            if dist.get_backend(self.pg) == 'nccl':
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            else:
+                g = self.grad.cpu()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
+                self.grad.copy_(g)
+            # the loss kernel already divided by the GLOBAL batch (it saw all ranks' logits): the sum over ranks is the gradient
+            lib.adam_step(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count,
+                          grad_scale=1.0, cursor_dev=cursor)
+
+    def _global_loss(self, bs, labels, cursor, loss_hist):
+        """qua_loss couples all samples of the batch (six batch-mean KL terms): every rank evaluates it on the logits of
+        ALL ranks (4*bs*world x K floats, a few tens of KB) and keeps its own rows of d loss / d logits."""
+        import torch.distributed as dist
+        W, K = self.world, self.logits.shape[1]
+        mine = self.logits[:4 * bs].contiguous()
+        if dist.get_backend(self.pg) == 'nccl':
+            parts = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(parts, mine, group=self.pg)
+        else:
+            host = [torch.empty(4 * bs, K) for _ in range(W)]
+            dist.all_gather(host, mine.cpu(), group=self.pg)
+            parts = [h.to(mine.device) for h in host]
+        # rank r holds [stream][bs] rows; the global batch is [stream][rank][bs]
+        glob = torch.stack([p.view(4, bs, K) for p in parts], 1).reshape(4 * W * bs, K).contiguous()
+        step = int(self.host_cursor)
+        glab = self.plan_labels_global[step * W * bs:(step + 1) * W * bs].contiguous()
+        gdl = torch.empty_like(glob)
+        lib.qua_loss(glob, W * bs, glab, self.params, loss=self.loss, dlogits=gdl)
+        if loss_hist is not None:
+            loss_hist[step:step + 1].copy_(self.loss)
+        self.dlogits[:4 * bs].copy_(gdl.view(4, W, bs, K)[:, self.rank].reshape(4 * bs, K))
 
     def step(self, xy, labels):
         """One step on the bs pixels `xy` [bs, 2] (host or device ints) with `labels` [bs]."""
+        if self.world > 1:
+            raise lib.DmfError('data-parallel stage 2 runs from a plan (load_plan / run_plan)')
         bs = int(xy.shape[0])
         if bs > self.bs:
             raise lib.DmfError('engine was built for batches of at most %d' % self.bs)
@@ -372,33 +436,86 @@ class QuaTrainEngine:
         xy4 = self.scene.stack_xy(torch.as_tensor(xy).cpu()).to(dev).contiguous()
         lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy4.cpu().numpy())
         lab = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).contiguous()
+        K = self.net.arch['K']
+        if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= K):
+            raise lib.DmfError('label outside [0, %d)' % K)
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy4)
         self._step(inp, bs, lab, None, None)
 
     def load_plan(self, xy_all, labels_all):
-        """An epoch of full batches: xy_all [n*bs, 2], labels_all [n*bs]."""
+        """An epoch of full GLOBAL batches: xy_all [n*bs*world, 2], labels_all [n*bs*world]; rank r trains on rows
+        [r*bs, (r+1)*bs) of every global batch."""
         dev = self.scene.device
+        W = self.world
         xy = torch.as_tensor(xy_all).to(torch.int32).cpu()
         lab = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
-        if xy.shape[0] % self.bs or xy.shape[0] != lab.shape[0]:
-            raise lib.DmfError('plan length must be a multiple of the batch size')
-        n = xy.shape[0] // self.bs
+        if xy.shape[0] % (self.bs * W) or xy.shape[0] != lab.shape[0]:
+            raise lib.DmfError('plan length must be a multiple of the (global) batch size')
+        n = xy.shape[0] // (self.bs * W)
         K = self.net.arch['K']
         if n and (int(lab.min()) < 0 or int(lab.max()) >= K):
             raise lib.DmfError('label outside [0, %d)' % K)
+        self.plan_labels_global = lab
+        if W > 1:
+            xy = xy.view(n, W, self.bs, 2)[:, self.rank].reshape(-1, 2)
+            lab = lab.view(n, W, self.bs)[:, self.rank].reshape(-1).contiguous()
         xy4 = torch.cat([self.scene.stack_xy(xy[i * self.bs:(i + 1) * self.bs]) for i in range(n)]) if n else xy
         lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xy4.numpy())
-        self.plan_xy, self.plan_labels = xy4.to(dev).contiguous(), lab
-        self.loss_hist = torch.zeros(max(n, 1), device=dev)
+        same = self.plan_xy is not None and self.plan_xy.shape == xy4.shape
+        if same:                                   # keep addresses stable for an already captured graph
+            self.plan_xy.copy_(xy4); self.plan_labels.copy_(lab)
+        else:
+            self.plan_xy, self.plan_labels = xy4.to(dev).contiguous(), lab
+            self.loss_hist = torch.zeros(max(n, 1), device=dev)
+            self.graph = None
+        self.loss_hist.zero_()
         self.dev_cursor.zero_()
+        self.host_cursor = 0
+        self.dev_step.fill_(self.step_count)
         self.plan_steps = n
         return n
 
-    def run_plan(self, steps=None):
+    def _plan_step(self):
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=4 * self.bs, cursor=self.dev_cursor)
+        self._step(inp, self.bs, self.plan_labels, self.dev_cursor, self.loss_hist, self.dev_step)
+        self.host_cursor += 1
+
+    def _capture(self, n):
+        """Capture n steps (unit-gradient form, one GPU).  hipFuncSetAttribute is not capturable: one eager step first,
+        then the exact pre-step state is put back (capture itself executes nothing)."""
+        if not self.unit or self.world > 1:
+            raise lib.DmfError('graph replay needs the unit-gradient step on one GPU')
+        state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
+        count0 = self.step_count
+        saved = [t.clone() for t in state]
+        self._plan_step()
+        torch.cuda.synchronize()
+        for t, s in zip(state, saved):
+            t.copy_(s)
+        self.step_count = count0
+        self.host_cursor -= 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=4 * self.bs, cursor=self.dev_cursor)
+                self._step(inp, self.bs, self.plan_labels, self.dev_cursor, self.loss_hist, self.dev_step)
+        self.step_count = count0
+        self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
+
+    def run_plan(self, steps=None, steps_per_graph=0):
         steps = self.plan_steps if steps is None else steps
-        for _ in range(steps):
-            inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=4 * self.bs, cursor=self.dev_cursor)
-            self._step(inp, self.bs, self.plan_labels, self.dev_cursor, self.loss_hist)
+        done = 0
+        if steps_per_graph > 0 and self.unit and self.world == 1:
+            if self.graph is None or self.graph_steps != steps_per_graph or self.graph_hparams != self._hparams():
+                self._capture(steps_per_graph)
+            while steps - done >= steps_per_graph:
+                self.graph.replay()
+                self.step_count += steps_per_graph
+                self.host_cursor += steps_per_graph
+                done += steps_per_graph
+        for _ in range(steps - done):
+            self._plan_step()
         return steps
 
     def losses(self):
@@ -406,9 +523,16 @@ class QuaTrainEngine:
 
     # bench.py: the step's dominant launch alone (for HIP-event timing) and its name
     def time_dominant(self, inp):
-        lib.backward_dlogits(self.shape, inp, self.theta, self.net.pool_w, self.dlogits, self.ws)
+        if self.unit:
+            lib.forward_unit(self.shape, inp, self.theta, self.net.pool_w, self.logits, self.ws)
+        else:
+            lib.backward_dlogits(self.shape, inp, self.theta, self.net.pool_w, self.dlogits, self.ws)
 
     def dominant_name(self):
+        a = self.net.arch
+        if self.unit:
+            return 'dmf::patch_v2_kernel<Shape<%d,%d,%d,1,%d,..>, MODE_UNIT> (dmf_forward_unit: forward + unit gradients of the 4*bs stacked patches)' % (
+                a['C'], a['C2'], a['P'], a['F'])
         return 'dmf::patch_kernel<ShapeQua, MODE_BWD> (dmf_backward_dlogits: forward recompute + backward of the 4*bs stacked patches)'
 
 

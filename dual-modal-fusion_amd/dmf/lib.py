@@ -56,6 +56,9 @@ def _load():
         'dmf_attn_train_workspace_bytes': (i64, [SP, i32]),
         'dmf_train_attn_fwd_bwd': (i32, [SP, IP, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
         'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
+        'dmf_unit_supported': (i32, [SP]),
+        'dmf_forward_unit': (i32, [SP, IP, vp, vp, vp, vp, vp, vp]),
+        'dmf_backward_unit': (i32, [SP, i32, vp, vp, vp, vp]),
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
         'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp]),
         'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
@@ -106,6 +109,20 @@ def shape_supported(shape):
 def patch_v2_used(shape, mode=1):
     """True if the train step (mode 1; 0 = forward, 2 = backward from dlogits) of this shape runs the v2 patch kernel."""
     return _lib.dmf_patch_variant(C.byref(shape), mode) == 2
+
+
+def unit_supported(shape):
+    """True if the two-launch unit-gradient step (forward_unit / backward_unit) exists for this shape."""
+    return _lib.dmf_unit_supported(C.byref(shape)) == 0
+
+
+def forward_unit(shape, inp, theta, pool_w, logits, ws, adam_step_dev=None):
+    check(_lib.dmf_forward_unit(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(logits), _ptr(ws),
+                                _ptr(adam_step_dev), _stream()))
+
+
+def backward_unit(shape, B, theta, dlogits, ws):
+    check(_lib.dmf_backward_unit(C.byref(shape), B, _ptr(theta), _ptr(dlogits), _ptr(ws), _stream()))
 
 
 def param_layout(shape):

@@ -90,7 +90,7 @@ class toStageSolver(Solver):
         losses = []
         if full:
             eng.load_plan(torch.cat([b[0] for b in full]), torch.cat([b[1] for b in full]))
-            eng.run_plan(len(full))
+            eng.run_plan(len(full), int(self.cfg.get('steps_per_graph', 0)) if eng.unit else 0)
             losses = eng.losses().tolist()
         for xy, lab in batches:
             if xy.shape[0] != B:                                             # DataLoader keeps the short last batch

@@ -119,6 +119,21 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* shape, const dmf_input* in, cons
                                float* logits, float* loss, void* workspace, void* attn_workspace,
                                int32_t* adam_step_dev, void* stream);
 
+/* The train step for a loss that couples the whole batch (qua_loss: tostagesolver.py:275-277), in two launches around the
+ * caller's loss kernel and WITHOUT a second pass over the patches:
+ *   dmf_forward_unit   forward (logits [B, K]) + the conv backward for a UNIT gradient on every pooled feature; leaves the
+ *                      head vectors and one row of unit gradients per patch in `workspace`
+ *   (loss kernel)      dL/dlogits [B, K] from the logits of the whole batch (dmf_qua_loss)
+ *   dmf_backward_unit  dh, dz per patch from dL/dlogits, slab rows = sum of dz x unit rows; then dmf_grad_reduce* as usual
+ * Exact, not an approximation: the net is piecewise linear and a feature channel reaches the head only through its two
+ * pooled scalars.  Returns non-zero for shapes without such a kernel (dmf_unit_supported; use dmf_forward +
+ * dmf_backward_dlogits there).  adam_step_dev as in dmf_train_fwd_bwd. */
+int32_t dmf_unit_supported(const dmf_shape* shape);
+int32_t dmf_forward_unit(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                         float* logits, void* workspace, int32_t* adam_step_dev, void* stream);
+int32_t dmf_backward_unit(const dmf_shape* shape, int32_t B, const float* theta, const float* dlogits, void* workspace,
+                          void* stream);
+
 /* Backward for a caller-supplied dL/dlogits [B, K] (the autograd path: torch computes the loss). */
 int32_t dmf_backward_dlogits(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                              const float* dlogits, void* workspace, void* stream);

@@ -22,6 +22,10 @@ SHAPES = {
     'panms': (4, 1, 16, 4, 12),
     'qua': (4, 1, 16, 1, 12),        # stage 2 of the two-stage path: one 4-band stream + its band mean
     'quatiny': (4, 1, 5, 1, 5),
+    # rows of the v2 shape table (csrc/dmf_patch_v2.hip, DMF_V2_SHAPES): other patch sizes of the two HSI nets
+    'hsi9': (200, 1, 9, 1, 17),
+    'hsi7': (200, 1, 7, 1, 17),
+    'hsi224p9': (224, 3, 9, 1, 17),
 }
 
 
@@ -29,7 +33,7 @@ def make_cfg(name):
     C, C2, P, S, K = SHAPES[name]
     return {'patch_size': P, 'Categories_Number': K, 'data_city': 's', 'DATA_DICT': {'s': {'size': [64, 64, C]}},
             'scale': S, 'aux_bands': C2,
-            'gmf': {'width': 32 if name in ('hsi224', 'hsi32') else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'gmf': {'width': 32 if name in ('hsi224', 'hsi32', 'hsi224p9') else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def nets(name, seed=0):
@@ -75,10 +79,13 @@ def assert_close(got, want, atol, rtol, what):
         np.unravel_index(int(err.argmax()), tuple(err.shape)) if err.dim() else ())
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
+ALL = ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny', 'hsi9', 'hsi7', 'hsi224p9']
+
+
+@pytest.mark.parametrize('name', ALL)
 @pytest.mark.parametrize('B', [1, 37, 300])
 def test_forward_patches(name, B):
-    if name in ('hsi224', 'hsi32', 'panms') and B == 300:
+    if name in ('hsi224', 'hsi32', 'panms', 'hsi224p9') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -97,7 +104,7 @@ def _scene(name, H=23, W=19, seed=5):
     return A, Bm
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
+@pytest.mark.parametrize('name', ALL)
 def test_forward_gather_and_pred(name):
     from dmf import lib
     C, C2, P, S, K = SHAPES[name]
@@ -126,11 +133,11 @@ def test_forward_gather_and_pred(name):
     assert torch.equal(pred.cpu().long()[safe], want.argmax(1)[safe])
 
 
-@pytest.mark.parametrize('name', ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny'])
+@pytest.mark.parametrize('name', ALL)
 @pytest.mark.parametrize('B', [3, 64, 300])
 def test_train_fwd_bwd_grads(name, B):
     from dmf import lib
-    if name in ('hsi224', 'hsi32', 'panms') and B == 300:
+    if name in ('hsi224', 'hsi32', 'panms', 'hsi224p9') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -180,6 +187,46 @@ def test_train_gather_equals_patches(name):
         outs.append((logits.cpu(), loss.cpu(), grad.cpu()))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('name', ['tiny1', 'hsi', 'qua', 'quatiny', 'hsi9'])
+@pytest.mark.parametrize('B', [5, 300])
+def test_unit_gradient_step_equals_autograd(name, B):
+    """The two-launch step for batch-coupled losses: dmf_forward_unit (forward + unit gradients per patch), a caller-made
+    dL/dlogits, dmf_backward_unit — against torch autograd of the oracle for the same upstream gradient, in gather mode."""
+    from dmf import lib
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    assert lib.unit_supported(hip.shape)
+    H, W = 23, 19
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(11)
+    xy = torch.stack([torch.randint(0, H, (B,), generator=g), torch.randint(0, W, (B,), generator=g)], 1).int()
+    dl = torch.randn(B, K, generator=g) / B
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    b = torch.stack([Bm[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    ref.zero_grad()
+    want_logits = ref(a, b)
+    want_logits.backward(dl)
+    want_g = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    inp = lib.input_gather(hip.shape, Ad, Bd, xyd)
+    theta = hip.flat_parameters()
+    logits = torch.empty(B, K, device='cuda')
+    ws = hip.workspace(B)
+    step = torch.zeros(1, dtype=torch.int32, device='cuda')
+    lib.forward_unit(hip.shape, inp, theta, hip.pool_w, logits, ws, adam_step_dev=step)
+    lib.backward_unit(hip.shape, B, theta, dl.cuda(), ws)
+    grad = torch.empty_like(theta)
+    lib.grad_reduce(hip.shape, B, ws, grad)
+    torch.cuda.synchronize()
+    assert int(step.item()) == 1
+    assert_close(logits, want_logits.detach(), 1e-5, 0, 'unit-step logits')
+    from model.gmfnet import PARAM_ORDER
+    off = hip._offsets
+    for i, k in enumerate(PARAM_ORDER):
+        gk = grad[off[i]:off[i] + want_g[k].numel()].view(want_g[k].shape)
+        assert_close(gk, want_g[k], 1e-5, 1e-4, 'unit-step grad %s [%s,B=%d]' % (k, name, B))
 
 
 @pytest.mark.parametrize('name', ['tiny', 'hsi'])

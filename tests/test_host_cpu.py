@@ -51,8 +51,10 @@ def test_param_layout_and_workspace():
         net.fc2.bias.add_(1.0)                       # parameters are views of the flat vector
     assert torch.equal(flat[off[11]:off[12]], net.fc2.bias.detach())
     lib.shape_supported(net.shape)
-    bad = dict(cfg, patch_size=7)
-    with pytest.raises(lib.DmfError):
+    lib.shape_supported(Net(dict(cfg, patch_size=7)).shape)      # instances of the v2 shape table (late fusion only)
+    lib.shape_supported(Net(dict(cfg, patch_size=9)).shape)
+    bad = dict(cfg, patch_size=13)                               # 13x13x200 floats do not fit a CU's LDS: no instance
+    with pytest.raises(lib.DmfError, match='compiled'):
         lib.shape_supported(Net(bad).shape)
 
 

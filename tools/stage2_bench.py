@@ -37,11 +37,12 @@ def main():
     xy = np.stack([g.integers(0, H, steps * bs), g.integers(0, W, steps * bs)], 1).astype(np.int32)
     lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
     eng.load_plan(xy, lab)
-    eng.run_plan(20)
+    spg = 50 if eng.unit and steps % 50 == 0 else 0        # captured hipGraph of 50 steps where the unit-gradient step exists
+    eng.run_plan(min(50, steps), spg)
     torch.cuda.synchronize()
-    eng.dev_cursor.zero_()
+    eng.load_plan(xy, lab)
     t0 = time.perf_counter()
-    eng.run_plan(steps)
+    eng.run_plan(steps, spg)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     losses = eng.losses().numpy()
