@@ -312,3 +312,50 @@ def test_xgmi_protocol_many_ranks_one_process(world):
         torch.cuda.synchronize()
         for d, f in bufs:
             lib.xgmi_free(d); lib.xgmi_free(f)
+
+
+# ---------------------------------------------------------------------------------------------- stage 2, data parallel
+QCFG = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [20, 20, 4]}},
+        'gmf': {'width': 40, 'single_input': 1}, 'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1}}
+
+
+def _train_stage2(rank, world, port, q):
+    """4 steps of the stage-2 engine on global batches of 24 pixels; world ranks take 24 / world each.  qua_loss couples the
+    whole batch, so the ranks gather their logits and evaluate it on the GLOBAL batch (engine.QuaTrainEngine._global_loss)."""
+    import torch.distributed as dist
+    sys.path[:0] = [PKG, REPO]
+    from dmf import synth
+    from dmf.engine import QuaScene, QuaTrainEngine
+    from function.function import data_padding
+    from model.gmfnet import Net
+    pg = None
+    if world > 1:
+        import datetime
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        pg = dist.group.WORLD
+    ms, pan, label = synth.make_scene(20, 20, 4, 1, 1, n_classes=4, seed=5)
+    g = np.random.default_rng(2)
+    scenes = [data_padding(x, QCFG, 'ms') for x in (ms, ms[::-1].copy(), ms + 0.1 * g.standard_normal(ms.shape), ms * 0.5)]
+    GB, NS = 24, 4
+    xy = np.stack([g.integers(0, 20, GB * NS), g.integers(0, 20, GB * NS)], 1).astype(np.int32)
+    lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
+    torch.manual_seed(0)
+    net = Net(QCFG).to('cuda:0')
+    eng = QuaTrainEngine(net, QuaScene(scenes, 'cuda:0'), GB // world, QCFG['dqtl'], lr=1e-2, process_group=pg)
+    eng.load_plan(xy, lab)
+    eng.run_plan(NS)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((eng.theta.cpu().numpy(), eng.loss_hist[:NS].cpu().numpy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_stage2_two_rank_dp_equals_single_rank_global_batch():
+    (two, l2), (one, l1) = _run_ranks(_train_stage2, 2, ()), _run_ranks(_train_stage2, 1, ())
+    err = np.abs(two - one).max()
+    print('stage 2: 2-rank vs 1-rank parameters after 4 steps: max abs diff %.2e; losses %s vs %s' % (err, l2, l1))
+    assert np.abs(l2 - l1).max() < 1e-5
+    assert err < 2e-5
