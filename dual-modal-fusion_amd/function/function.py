@@ -54,6 +54,24 @@ def split_data_old(label, cfg):
     return the_matrix, matrix_
 
 
+def split_data(train_label, test_label, label, cfg):
+    """function.py:172-194 of the reference (`data_new: 1`): the row-major pixel table of the whole scene and three index
+    lists — pixels in neither mask, pixels of the TRAIN mask, pixels of the TEST mask only (a pixel in both counts as
+    train: the reference's `if train ... elif test`)."""
+    size = cfg['DATA_DICT'][cfg['data_city']]['size']
+    H, W = int(size[0]), int(size[1])
+    lab = np.asarray(label)[:H, :W]
+    tr = np.asarray(train_label)[:H, :W].reshape(-1) != 0
+    te = np.asarray(test_label)[:H, :W].reshape(-1) != 0
+    xs, ys = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    the_matrix = [xs.reshape(-1, 1).astype(np.float64), ys.reshape(-1, 1).astype(np.float64),
+                  lab.reshape(-1, 1).astype(np.float64)]
+    matrix_ = [np.nonzero(~tr & ~te)[0].tolist(), np.nonzero(tr)[0].tolist(), np.nonzero(~tr & te)[0].tolist()]
+    for i in range(3):
+        print("label set {} size {}".format(i, len(matrix_[i])))
+    return the_matrix, matrix_
+
+
 def read_tif(cfg, mode):
     if mode == 'ms':
         filename = cfg['data_address'] + 'ms4.tif'

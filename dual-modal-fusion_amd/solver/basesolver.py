@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Subset
 
-from function.function import data_padding, data_padding_aux, data_show, label_mat2np, read_tif, split_data_old
+from function.function import data_padding, data_padding_aux, data_show, label_mat2np, read_tif, split_data, split_data_old
 from indicators.kappa import aa_oa, expo_result
 from train.dataset import dataset_dual
 
@@ -42,9 +42,14 @@ class BaseSolver:
         label_np = np.load(label_path)
         data_show(label_np)
         self.label_np = label_np
-        if cfg.get('data_new') == 1:
-            raise NotImplementedError('data_new: 1 (separate train.npy / test.npy masks) is not built yet')
-        xyl_matrix, self.matrix_ = split_data_old(label_np, cfg)
+        self.data_new = cfg.get('data_new') == 1
+        if self.data_new:                                       # basesolver.py:28-30,38-40: fixed train / test masks
+            self.train_label = np.load(cfg['data_address'] + 'train.npy')
+            self.test_label = np.load(cfg['data_address'] + 'test.npy')
+            xyl_matrix, self.traintest_index = split_data(self.train_label, self.test_label, label_np, cfg)
+            _, self.matrix_ = split_data_old(label_np, cfg)
+        else:
+            xyl_matrix, self.matrix_ = split_data_old(label_np, cfg)
         self.xyl = xyl_matrix
         if cfg.get('use_h5'):
             raise AttributeError("not finished")          # as the reference (basesolver.py:45-46)
@@ -65,6 +70,26 @@ class BaseSolver:
 
     def dataloader(self):
         cfg = self.cfg
+        if self.data_new:
+            # basesolver.py:64-84: the whole train mask trains; the test mask is split (global RNG) into test / valid
+            train_data = Subset(self.dataset, indices=self.traintest_index[1])
+            test_data = Subset(self.dataset, indices=self.traintest_index[2])
+            valid_size = int(cfg['verify_rate'] * len(test_data))
+            test_size = len(test_data) - valid_size
+            test_dataset, valid_dataset = torch.utils.data.random_split(test_data, [test_size, valid_size])
+            base = np.asarray(self.traintest_index[2])
+
+            def flat2(s):
+                return Subset(self.dataset, indices=base[np.asarray(s.indices)].tolist())
+
+            self.train_loader, self.train_index_loader = self._loader(train_data, cfg['batchsize'], True)
+            self.test_loader, self.test_index_loader = self._loader(flat2(test_dataset), cfg['test_batchsize'], False)
+            self.valid_loader, self.valid_index_loader = self._loader(flat2(valid_dataset), cfg['color_batchsize'], False)
+            self.color_loader1, self.color_index_loader1 = self._loader(Subset(self.dataset, indices=self.matrix_[1]),
+                                                                        cfg['test_batchsize'], False)
+            self.color_loader2, self.color_index_loader2 = self._loader(Subset(self.dataset, indices=self.matrix_[0]),
+                                                                        cfg['test_batchsize'], False)
+            return
         train_data = Subset(self.dataset, indices=self.matrix_[1])
         train_size = int(cfg['train_rate'] * len(train_data))
         valid_size = int(cfg['verify_rate'] * len(train_data))

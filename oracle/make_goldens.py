@@ -15,6 +15,7 @@ What is imported from /root/reference and how
 Fixtures (SURVEY.md §8c list):
   g1_to_tensor.npz        to_tensor on a 6x7x5 cube                         (function.py:120-124)
   g2_split.npz            split_data_old tables on a 7x9 label map           (function.py:149-169)
+  g2b_split_new.npz       split_data (data_new: 1) on fixed train / test masks  (function.py:172-194)
   g3_dataset.npz          dataset_dual[i] tuples                             (dataset.py:158-188)
   g5_ce_adam.npz          CrossEntropyLoss value/grad, Adam one step, ExponentialLR (utils/utils.py)
   g6_kappa.json           kappa / aa_oa on fixed matrices                    (kappa.py:10-22,69-84)
@@ -82,6 +83,15 @@ def main():
     the_matrix, matrix_ = rf.split_data_old(lab, cfg2)
     np.savez(os.path.join(OUT, 'g2_split.npz'), label=lab, x=the_matrix[0], y=the_matrix[1], l=the_matrix[2],
              idx0=np.array(matrix_[0]), idx1=np.array(matrix_[1]))
+
+    # ---- G2b  `data_new: 1`: split_data on fixed train / test masks (function.py:172-194).  Drawn from a generator of its
+    #           own so that the stream behind G3.. is unchanged.
+    rng2 = np.random.default_rng(70)
+    tr_mask = (rng2.random((7, 9)) < 0.3).astype(np.uint8) * lab.clip(0, 1)
+    te_mask = (rng2.random((7, 9)) < 0.5).astype(np.uint8) * lab.clip(0, 1)       # overlaps the train mask on purpose
+    m_new, idx_new = rf.split_data(tr_mask, te_mask, lab, cfg2)
+    np.savez(os.path.join(OUT, 'g2b_split_new.npz'), label=lab, train=tr_mask, test=te_mask, x=m_new[0], y=m_new[1], l=m_new[2],
+             idx0=np.array(idx_new[0]), idx1=np.array(idx_new[1]), idx2=np.array(idx_new[2]))
 
     # ---- G3   (reference geometry: PAN at 4x, dataset.py:166,173-176)
     p = 3

@@ -318,3 +318,76 @@ def test_shard_ranges_cover_everything_once():
     assert shard_batch(512, 3, 8) == (192, 256)
     with pytest.raises(ValueError):
         shard_batch(10, 0, 4)
+
+
+def test_split_data_new_against_golden_and_loaders(golden_dir):
+    """`data_new: 1` (reference basesolver.py:28-30,38-40,64-84; function.py:172-194): fixed train / test masks.  The index
+    lists match the REAL reference's `split_data` (G2b); the solver trains on the whole train mask and splits only the
+    test mask into test / valid."""
+    from function.function import split_data
+    g = _g(golden_dir, 'g2b_split_new.npz')
+    cfg2 = {'DATA_DICT': {'t': {'size': [7, 9, 5]}}, 'data_city': 't'}
+    m, idx = split_data(g['train'], g['test'], g['label'], cfg2)
+    assert all(np.array_equal(a, g[k]) and a.dtype == np.float64 for a, k in zip(m, 'xyl'))
+    for i in range(3):
+        assert idx[i] == g['idx%d' % i].tolist()
+    assert set(idx[1]) & set(idx[2]) == set()                      # a pixel in both masks counts as train
+
+    from solver.mainsolver import Solver
+    tmp = tempfile.mkdtemp(prefix='dmf_cpu_')
+    try:
+        g9, cfg = _golden_scene_dir(golden_dir, tmp)
+        lab = g9['label']
+        rng = np.random.default_rng(0)
+        tr = ((rng.random(lab.shape) < 0.2) & (lab != 0)).astype(np.uint8)
+        te = ((rng.random(lab.shape) < 0.6) & (lab != 0)).astype(np.uint8)
+        np.save(cfg['data_address'] + 'train.npy', tr); np.save(cfg['data_address'] + 'test.npy', te)
+        cfg.update(device='cpu', data_new=1)
+        torch.manual_seed(3407)
+        s = Solver(cfg)
+        s.dataloader()
+        H, W = cfg['DATA_DICT'][cfg['data_city']]['size'][:2]
+        tr_idx = np.nonzero(tr[:H, :W].reshape(-1))[0]
+        te_idx = np.nonzero((te[:H, :W].reshape(-1) != 0) & (tr[:H, :W].reshape(-1) == 0))[0]
+        assert np.array_equal(np.array(s.train_loader.dataset.indices), tr_idx)
+        got_test, got_valid = np.array(s.test_loader.dataset.indices), np.array(s.valid_loader.dataset.indices)
+        assert len(got_valid) == int(cfg['verify_rate'] * len(te_idx)) and len(got_test) == len(te_idx) - len(got_valid)
+        assert sorted(got_test.tolist() + got_valid.tolist()) == te_idx.tolist()
+        # the index twin walks the same pixels in the same order as the materialising loader
+        assert [int(i) for b in s.test_index_loader for i in b[3]] == got_test.tolist()
+        assert np.array_equal(np.array(s.color_loader1.dataset.indices), np.array(s.matrix_[1]))
+    finally:
+        shutil.rmtree(tmp)
+
+
+def test_testsolver_and_dataloaderx(golden_dir):
+    """J1 entry points on the host: `Testsolver(cfg)` completes the reference's truncated stub (solver/testsolver.py:9-15:
+    loads `model.<cfg['algorithm']>` and takes `lib.Net`); `DataLoaderX` (train/dataloader.py:6-8) yields exactly what
+    the plain DataLoader yields, prefetched by a background thread, and surfaces worker errors.  (Its evaluation run
+    needs the GPU: tests/test_gpu_trajectory.py::test_testsolver_evaluates_saved_weights.)"""
+    from solver.testsolver import Testsolver
+    from train.dataloader import DataLoaderX
+    tmp = tempfile.mkdtemp(prefix='dmf_cpu_')
+    try:
+        g, cfg = _golden_scene_dir(golden_dir, tmp)
+        cfg.update(device='cpu', algorithm=cfg.get('model_name', 'gmfnet'))
+        t = Testsolver(cfg)
+        import model.gmfnet
+        assert t.net_class is model.gmfnet.Net
+        ds = t.index_dataset
+        plain = [tuple(int(v) for v in x[3]) for x in torch.utils.data.DataLoader(ds, batch_size=7, shuffle=False)]
+        pref = [tuple(int(v) for v in x[3]) for x in DataLoaderX(ds, batch_size=7, shuffle=False)]
+        assert pref == plain and len(pref) == -(-len(ds) // 7)
+
+        class Boom(torch.utils.data.Dataset):
+            def __len__(self):
+                return 4
+
+            def __getitem__(self, i):
+                if i == 2:
+                    raise ValueError('bad item')
+                return torch.tensor(i)
+        with pytest.raises(ValueError, match='bad item'):
+            list(DataLoaderX(Boom(), batch_size=1))
+    finally:
+        shutil.rmtree(tmp)
