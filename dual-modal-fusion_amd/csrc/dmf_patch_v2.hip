@@ -382,10 +382,14 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   auto issue_gather = [&](int x, int y) {
     const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * Sh::C;
     const int rowskip = (a.in.Wp - P) * Sh::C;               // floats between the end of a window row and the start of the next
+    int l_ = lane;
+    OPAQUE(l_);                                              // offsets are formed here, per patch: hoisted out of the patch loop
+                                                             // they are spilled, and a scratch reload in front of a piece
+                                                             // waits for every piece issued before it
 #pragma unroll
     for (int k = 0; k < V::NK; ++k) {
       const int p = wave + k * V::NW;
-      const int n = 256 * p + 4 * lane;
+      const int n = 256 * p + 4 * l_;
       int off;
       if constexpr (V::CS == Sh::C) {                        // unpadded pixels: a window row is one contiguous run of the scene
         const int pr = n / V::RS, within = n - pr * V::RS;

@@ -48,7 +48,8 @@ def main():
             pmc.setdefault(k, {})[ctr] = {'n': len(v), 'median_KiB': statistics.median(v), 'mean_KiB': statistics.mean(v)}
     summary = {'round': tag, 'kernels': pmc}
     for k, v in pmc.items():
-        if 'patch_kernel' in k and ', 1>' in k and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+        train = ('patch_kernel' in k and ', 1>' in k) or ('patch_v2_kernel' in k and ', 1, 1>' in k)     # MODE_TRAIN (gather input)
+        if train and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             fetch = 2 * v['FETCH_SIZE']['median_KiB'] * 1024
             write = v['WRITE_SIZE']['median_KiB'] * 1024
             summary['patch_kernel_hbm_bytes_per_launch'] = fetch + write
