@@ -54,7 +54,7 @@ def make_cfg(args):
     return {'patch_size': args.patch, 'Categories_Number': K, 'data_city': 'syn',
             'DATA_DICT': {'syn': {'size': [args.size, args.size, args.bands], 'color': class_colors(K)}},
             'scale': args.scale, 'aux_bands': args.aux_bands,
-            'gmf': {'width': args.width, 'hidden': 64, 'pool_sigma': 2.5, 'attention': args.attention},
+            'gmf': {'width': args.width, 'hidden': 64, 'pool_sigma': 2.5, 'attention': args.attention, 'half': args.half},
             'trans': {'embed_dim': 96, 'num_head': 3}}
 
 
@@ -131,6 +131,9 @@ def main():
     for k, t in (('batch', int), ('size', int), ('bands', int), ('aux-bands', int), ('width', int), ('patch', int),
                  ('scale', int), ('classes', int), ('attention', int)):
         ap.add_argument('--' + k, type=t, default=None, help='overrides the --config value')
+    ap.add_argument('--half', type=int, default=None, choices=[0, 1],
+                    help='fp16 primary scene + fp16 spec_a operands (fp32 accumulate) + device loss scaler; default: 1 for '
+                         '--config 4 (BASELINE configs[4]: "fp16 mixed precision"), else 0 (the fp32 headline)')
     ap.add_argument('--train-rate', type=float, default=0.10)
     ap.add_argument('--steps-per-graph', type=int, default=50, help='0 = eager launches')
     ap.add_argument('--kappa-steps', type=int, default=2200, help='train to this many steps (from the initial weights) before kappa')
@@ -142,6 +145,8 @@ def main():
             setattr(args, k, v)
     if args.bands == 224 and args.width == 40:
         args.width = 32                     # the compiled 224-band instance
+    if args.half is None:
+        args.half = 1 if args.config == '4' else 0
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -174,7 +179,7 @@ def main():
         return main_stage2(args, dev)
 
     from dmf import lib
-    from dmf.engine import EvalEngine, Scene, TrainEngine
+    from dmf.engine import EvalEngine, LossScaler, Scene, TrainEngine
     from model.gmfnet import Net
 
     cfg = make_cfg(args)
@@ -184,15 +189,16 @@ def main():
     torch.manual_seed(3407)
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    scene = Scene(MS, PAN, dev)
+    scene = Scene(MS, PAN, dev, half=bool(args.half))
+    scaler = lambda: LossScaler(dev) if args.half else None      # (GradScaler defaults: 65536, x2 / x0.5, every 2000)
     comm = None
     # N > 2 has only ever been exercised with all ranks on ONE GPU (tests/test_gpu_dp.py); the exchange is admitted per run
     # by the checks below and the RCCL all-reduce is the fallback
-    if world > 1 and os.environ.get('DMF_ALLREDUCE', 'xgmi') == 'xgmi':
+    if world > 1 and os.environ.get('DMF_ALLREDUCE', 'xgmi') == 'xgmi' and not args.half:
         from dmf import xgmi
         comm = xgmi.create(sum(p.numel() for p in net.parameters()), pg,     # None on every rank if it cannot be proven
                            timeout_ms=int(os.environ.get('DMF_XGMI_TIMEOUT_MS', 20000)))
-    eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=comm)
+    eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=comm, scaler=scaler())
 
     total = W_steps + K_steps
     plan_steps = max(total, args.kappa_steps)
@@ -231,7 +237,7 @@ def main():
                 print('[bench] %s; falling back to the RCCL all-reduce' % exchange_note, file=sys.stderr, flush=True)
             comm = None
             net.load_state_dict(init_state)
-            eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=None)
+            eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=None, scaler=scaler())
             eng.load_plan(xy_tab[mine], lab_tab[mine])
             spg = 0
             eng.run_plan(W_steps, 0)
@@ -257,7 +263,7 @@ def main():
 
     # ---- instrumented pass: mean duration of the dominant kernel, HIP events on the launch stream
     n_inst = min(K_steps, 200)
-    alg_patch = 2 * 4 * (P * P * C + (S * P) * (S * P) * C2)
+    alg_patch = 2 * ((2 if args.half else 4) * P * P * C + 4 * (S * P) * (S * P) * C2)     # --half: the primary bands are 2 bytes
     kern_ms = None
     if rank == 0 or world > 1:
         inst_plan_xy = torch.from_numpy(xy_tab[mine[:n_inst * B]]).to(dev)
@@ -318,13 +324,15 @@ def main():
         achieved = B * alg_patch / (kern_ms * 1e-3)
         roof = {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                 'traffic': traffic,
-                'kernel': 'dmf::%s<Shape<%d,%d,%d,%d,%d,..>, MODE_TRAIN>' % ('patch_v2_kernel' if v2 else 'patch_kernel', C, C2, P, S, net.arch['F']),
+                'kernel': 'dmf::%s<Shape<%d,%d,%d,%d,%d,..>, MODE_TRAIN%s>' % ('patch_v2_kernel' if v2 or args.half else 'patch_kernel', C, C2, P, S,
+                                                                          net.arch['F'], ', fp16 scene' if args.half else ''),
                 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': B * alg_patch}
     out = {
         'metric': 'training patches/sec + kappa, 11x11x200 HSI + 11x11x1 SAR, 1/2/4/8 MI355X',
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': K_steps, 'warmup': W_steps,
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if not args.attention else 'f32 (attention operands bf16, f32 accumulate)', 'data': 'synthetic',
+        'dtype': ('f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32')
+                 if not args.attention else 'f32 (attention operands bf16, f32 accumulate)', 'data': 'synthetic',
         'config': {'workload': '%s; %dx%d patches, %d logits, batch %d per GPU, fused HIP fwd+loss+bwd+Adam'
                                % (CONFIGS[args.config]['name'], P, P, args.classes + 1, B),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch,
@@ -389,7 +397,7 @@ def main():
             m_cpu, _ = solver_ref.evaluate(ref, MS, PAN, xy_tab[test[:n_kt]], lab_tab[test[:n_kt]], args.classes + 1, P, S)
             net2 = Net(cfg).to(dev)
             net2.load_state_dict(init_state)
-            eng2 = TrainEngine(net2, scene, B, lr=1e-3)
+            eng2 = TrainEngine(net2, scene, B, lr=1e-3, scaler=scaler())
             eng2.load_plan(xy_tab[mine[:n_k * B]], lab_tab[mine[:n_k * B]])
             eng2.run_plan(n_k, 0)
             m_gpu = EvalEngine(net2, scene, 2048).confusion(xy_tab[test[:n_kt]], lab_tab[test[:n_kt]]).cpu().numpy().astype(np.float64)
@@ -408,14 +416,14 @@ def main_stage2(args, dev):
     """--config 4: the stage-2 step of the two-stage path (solver/tostagesolver.py:259-315): four stacked streams through the
     one-input net, qua_loss, backward, ADAM.  A step processes 4*bs stacked patches; `value` counts those."""
     from dmf import lib, synth
-    from dmf.engine import QuaScene, QuaTrainEngine
+    from dmf.engine import LossScaler, QuaScene, QuaTrainEngine
     from function.function import data_padding
     from image_convert.IHS import pan2ms_gpu
     from model.gmfnet import Net
     H = W = args.size
     bs, K_steps, W_steps = args.batch, args.steps, args.warmup
     cfg = {'patch_size': args.patch, 'Categories_Number': args.classes + 1, 'data_city': 's', 'DATA_DICT': {'s': {'size': [H, W, 4]}},
-           'gmf': {'width': args.width, 'single_input': 1}, 'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1}}
+           'gmf': {'width': args.width, 'single_input': 1, 'half': args.half}, 'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1}}
     ms, pan, label = synth.make_scene(H, W, 4, 1, 4, n_classes=args.classes, seed=0)
     pan4 = pan2ms_gpu(pan, [H, W, 4])
     g = np.random.default_rng(1)
@@ -423,8 +431,9 @@ def main_stage2(args, dev):
     torch.manual_seed(0)
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    scene = QuaScene(scenes, dev)
-    eng = QuaTrainEngine(net, scene, bs, cfg['dqtl'], lr=1e-3)
+    scene = QuaScene(scenes, dev, half=bool(args.half))
+    sc = LossScaler(dev) if args.half else None        # GradScaler's defaults (tostagesolver.py:83-84)
+    eng = QuaTrainEngine(net, scene, bs, cfg['dqtl'], lr=1e-3, scaler=sc)
     total = W_steps + K_steps
     xy = np.stack([g.integers(0, H, total * bs), g.integers(0, W, total * bs)], 1).astype(np.int32)
     lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
@@ -444,7 +453,7 @@ def main_stage2(args, dev):
     dt = time.perf_counter() - t0
     losses = eng.losses().numpy()
     P = args.patch
-    alg_patch = 2 * 4 * (P * P * 4 + P * P * 1)
+    alg_patch = 2 * ((2 if args.half else 4) * P * P * 4 + 4 * P * P * 1)
     # dominant kernel: the forward(+unit-gradient) patch kernel over the 4*bs stacked patches, HIP events on the launch stream
     n_inst = min(K_steps, 100)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_inst)]
@@ -459,7 +468,8 @@ def main_stage2(args, dev):
     out = {
         'metric': 'training patches/sec + kappa, 11x11x200 HSI + 11x11x1 SAR, 1/2/4/8 MI355X',
         'value': 4 * bs * K_steps / dt, 'unit': 'patches/s', 'n_gpus': 1, 'steps': K_steps, 'warmup': W_steps,
-        'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32',
         'data': 'synthetic',
         'config': {'workload': '%s; %dx%d patches, %d logits, bs %d (%d stacked patches per step), qua_loss, fused HIP step'
                                % (CONFIGS['4']['name'], P, P, args.classes + 1, bs, 4 * bs),
@@ -469,6 +479,8 @@ def main_stage2(args, dev):
                      'kernel': eng.dominant_name(), 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': 4 * bs * alg_patch},
         'loss_first_last': [float(losses[0]), float(losses[-1])] if losses.size else None,
     }
+    if sc is not None:
+        out['loss_scaler'] = {'scale': sc.get_scale(), 'skipped_steps': sc.skipped_steps()}
     if not args.no_cpu:
         from oracle.gmfnet_ref import Net as RefNet
         from oracle import solver_ref

@@ -46,6 +46,7 @@ struct ReduceArgs {
   const float* aslab; int nablk, ASLAB; int64_t oAttn;   // attention weights: sum of the attention kernel's slabs
   XgmiDev x;                          // x.world > 1: exchange the gradient with the peer ranks before Adam
   float grad_scale; int seq_bias;
+  float* scaler;                      // loss-scaler state (dmf_grad_reduce_scaled): grad <- sum / scaler[0], non-finite -> scaler[2]
 };
 
 // bias corrections from a device-resident step count, in double like torch's host-side scalars
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
   }
   if (a.x.world > 1)                                 // block-uniform: every thread takes part in the barriers
     g = xgmi_exchange(a.x, 0, *a.step_dev + a.seq_bias, blockIdx.x, p, ch == 0 && p < a.n, g) * a.grad_scale;
+  if (a.scaler != nullptr && ch == 0 && p < a.n) {     // unscale_ + the found_inf check of GradScaler, in the reduce
+    g *= 1.f / a.scaler[0];
+    if (!isfinite(g)) a.scaler[2] = 1.f;               // (every writer stores the same value)
+  }
   if (ch == 0 && p < a.n) {
     if (a.grad != nullptr) a.grad[p] = g;
     if (a.theta != nullptr) {
@@ -179,6 +184,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float* theta, const float* gr
   if (step_dev != nullptr) bias_corrections(*step_dev, b1, b2, bc1, bc2_sqrt);
   if (p < n) adam_update(theta, m, v, p, grad[p] * grad_scale, lr, b1, b2, eps, bc1, bc2_sqrt);
   if (cursor_dev != nullptr && p == 0) *cursor_dev += 1;
+}
+
+// ------------------------------------------------------------------------------ dynamic loss scaling (GradScaler's role)
+// state: [0] scale  [1] growth tracker  [2] found_inf  [3] skipped steps  [4] ticket (int bits)
+__global__ __launch_bounds__(256) void unscale_check_kernel(float* grad, int64_t n, float grad_scale, float* state) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float g = grad[p] * (grad_scale / state[0]);
+  grad[p] = g;
+  if (!isfinite(g)) state[2] = 1.f;                 // (every writer stores the same value)
+}
+
+__global__ __launch_bounds__(256) void scaled_adam_kernel(float* theta, const float* grad, float* m, float* v, int64_t n,
+                                                          float lr, float b1, float b2, float eps, float* state,
+                                                          float growth, float backoff, int interval,
+                                                          int32_t* step_dev, int32_t* cursor_dev) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool skip = state[2] != 0.f;
+  if (!skip && p < n) {
+    float bc1, bc2s;
+    bias_corrections(*step_dev, b1, b2, bc1, bc2s);
+    adam_update(theta, m, v, p, grad[p], lr, b1, b2, eps, bc1, bc2s);
+  }
+  // the last block to get here has seen every other block read found_inf and the step count: it closes the step
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    int* ticket = reinterpret_cast<int*>(state + 4);
+    if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+      *ticket = 0;
+      if (skip) {
+        state[0] *= backoff; state[1] = 0.f; state[3] += 1.f;
+        *step_dev -= 1;                               // a skipped step does not count for the bias corrections
+      } else {
+        const float t = state[1] + 1.f;
+        if (t >= (float)interval) { state[0] *= growth; state[1] = 0.f; }
+        else state[1] = t;
+      }
+      state[2] = 0.f;
+      if (cursor_dev != nullptr) *cursor_dev += 1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------ eval helpers
@@ -258,10 +305,11 @@ int64_t dmf_workspace_bytes(const dmf_shape* s, int32_t B) {
 
 static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const float* theta, const float* pool_w,
                      const int32_t* labels, const float* dlogits, float loss_scale, float* logits, float* loss,
-                     int32_t* pred, void* workspace, int32_t* adam_step, void* stream) {
+                     int32_t* pred, void* workspace, int32_t* adam_step, void* stream, const float* scaler = nullptr) {
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr) return fail("%s", "null argument");
   if (dmf_shape_supported(s)) return 1;
   if (s->attention) return fail("%s", "attention network: use dmf_forward_attn / dmf_train_attn_fwd_bwd");
+  if (in->half && dmf_half_supported(s)) return 1;
   if (in->B < 0) return fail("%s", "negative batch");
   if (in->B == 0) return 0;
   if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");
@@ -275,6 +323,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
   a.labels = labels;
   a.dlogits = dlogits;
   a.loss_scale = loss_scale;
+  a.scaler = scaler;
   a.logits = logits;
   a.loss = loss;
   a.pred = pred;
@@ -292,7 +341,7 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
     a.ws_dl = ws + w.dl;
   }
   // the wave-per-channel-block kernel where it is built for the shape; DMF_PATCH_V1=1 forces the generic kernel (A/B runs)
-  if (!force_v1() && patch_v2_supported(*s, mode))
+  if (in->half || (!force_v1() && patch_v2_supported(*s, mode)))
     return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel (v2) launch");
   return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }
@@ -309,6 +358,7 @@ int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* t
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || workspace == nullptr || logits == nullptr)
     return fail("%s", "null argument");
   if (!s->attention) return fail("%s", "dmf_forward_attn needs shape->attention == 1");
+  if (in->half) return fail("%s", "fp16 scenes (dmf_input.half): late-fusion network only");
   if (dmf_shape_supported(s)) return 1;
   if (!attn_shape_supported(*s)) return fail("%s", "no compiled attention instance for this shape (E = 96, heads = 3, F = 40)");
   if (in->B <= 0) return in->B == 0 ? 0 : fail("%s", "negative batch");
@@ -348,6 +398,7 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
     return fail("%s", "null argument");
   if ((labels == nullptr) == (dlogits == nullptr)) return fail("%s", "give exactly one of labels / dlogits");
   if (!s->attention) return fail("%s", "dmf_train_attn_fwd_bwd needs shape->attention == 1");
+  if (in->half) return fail("%s", "fp16 scenes (dmf_input.half): late-fusion network only");
   if (dmf_shape_supported(s)) return 1;
   if (!attn_shape_supported(*s)) return fail("%s", "no compiled attention instance for this shape (E = 96, heads = 3, F = 40)");
   if (in->B <= 0) return in->B == 0 ? 0 : fail("%s", "negative batch");
@@ -401,6 +452,49 @@ int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* 
   return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace, adam_step_dev, stream);
 }
 
+int32_t dmf_train_fwd_bwd_scaled(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
+                                 const int32_t* labels, float loss_scale, const float* scaler_state, float* logits,
+                                 float* loss, void* workspace, int32_t* adam_step_dev, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
+  if (labels == nullptr || logits == nullptr || loss == nullptr || scaler_state == nullptr)
+    return fail("%s", "null labels/logits/loss/scaler_state");
+  return run_patch(s, in, MODE_TRAIN, theta, pool_w, labels, nullptr, loss_scale, logits, loss, nullptr, workspace,
+                   adam_step_dev, stream, scaler_state);
+}
+
+int32_t dmf_scaler_init(float* state, float init_scale, void* stream) {
+  if (state == nullptr || !(init_scale > 0.f)) return fail("%s", "scaler: null state or non-positive scale");
+  const float h[DMF_SCALER_FLOATS] = {init_scale, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (check(hipMemcpyAsync(state, h, sizeof(h), hipMemcpyHostToDevice, st), "scaler init")) return 1;
+  return check(hipStreamSynchronize(st), "scaler init");       // (h is a stack buffer)
+}
+
+int32_t dmf_unscale_adam(float* theta, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float grad_scale, float* scaler_state, float growth_factor, float backoff_factor,
+                         int32_t growth_interval, int32_t unscaled, int32_t* adam_step_dev, int32_t* cursor_dev, void* stream) {
+  if (theta == nullptr || grad == nullptr || m == nullptr || v == nullptr || scaler_state == nullptr || adam_step_dev == nullptr)
+    return fail("%s", "null argument (dmf_unscale_adam needs the device step count)");
+  if (n <= 0 || growth_interval < 1 || !(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f))
+    return fail("%s", "unscale_adam: bad n / growth_interval / factors");
+  const unsigned nblk = (unsigned)((n + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!unscaled) {
+    hipLaunchKernelGGL(unscale_check_kernel, dim3(nblk), dim3(256), 0, st, grad, n, grad_scale, scaler_state);
+    if (check(hipGetLastError(), "unscale launch")) return 1;
+  }
+  hipLaunchKernelGGL(scaled_adam_kernel, dim3(nblk), dim3(256), 0, st, theta, grad, m, v, n, lr, beta1, beta2, eps,
+                     scaler_state, growth_factor, backoff_factor, growth_interval, adam_step_dev, cursor_dev);
+  return check(hipGetLastError(), "scaled adam launch");
+}
+
+int32_t dmf_half_supported(const dmf_shape* s) {
+  if (s == nullptr) return fail("%s", "null shape");
+  if (s->attention || !patch_v2_supported(*s, MODE_TRAIN, 1))
+    return fail("no fp16-scene kernel for this shape (instances C/C2/P/S/F/G:%s)", patch_v2_half_shape_list());
+  return 0;
+}
+
 int32_t dmf_unit_supported(const dmf_shape* s) {
   if (s == nullptr) return fail("%s", "null shape");
   if (force_v1() || s->attention || !patch_v2_supported(*s, MODE_UNIT))
@@ -413,6 +507,7 @@ int32_t dmf_forward_unit(const dmf_shape* s, const dmf_input* in, const float* t
   if (s == nullptr || in == nullptr || theta == nullptr || pool_w == nullptr || logits == nullptr || workspace == nullptr)
     return fail("%s", "null argument");
   if (dmf_unit_supported(s)) return 1;
+  if (in->half && dmf_half_supported(s)) return 1;
   if (in->B < 0) return fail("%s", "negative batch");
   if (in->B == 0) return 0;
   if (in->mode == 0 && (in->a == nullptr || in->b == nullptr)) return fail("%s", "mode 0 needs a and b");
@@ -475,7 +570,7 @@ static int fill_xgmi(const dmf_xgmi_comm* c, XgmiDev& x) {
 static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, float* theta, float* m,
                       float* v, float lr, float b1, float b2, float eps, int32_t step, const int32_t* step_dev,
                       int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream,
-                      const dmf_xgmi_comm* comm = nullptr, float grad_scale = 1.f) {
+                      const dmf_xgmi_comm* comm = nullptr, float grad_scale = 1.f, float* scaler = nullptr) {
   if (s == nullptr || workspace == nullptr) return fail("%s", "null argument");
   if (B <= 0) return fail("%s", "batch must be positive");
   const Layout L = layout_of(*s);
@@ -497,6 +592,7 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
   }
   a.step_dev = step_dev; a.cursor_dev = cursor_dev; a.loss = loss; a.loss_hist = loss_hist;
   a.grad_scale = grad_scale;
+  a.scaler = scaler;
   if (comm != nullptr) {
     if (step_dev == nullptr) return fail("%s", "the xgmi exchange needs adam_step_dev");
     if (comm->capacity < L.n_params) return fail("%s", "xgmi communicator smaller than the parameter vector");
@@ -511,6 +607,13 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
 int32_t dmf_grad_reduce(const dmf_shape* s, int32_t B, const void* workspace, float* grad, void* stream) {
   if (grad == nullptr) return fail("%s", "null grad");
   return run_reduce(s, B, workspace, grad, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int32_t dmf_grad_reduce_scaled(const dmf_shape* s, int32_t B, const void* workspace, float* grad, float* scaler_state,
+                               int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream) {
+  if (grad == nullptr || scaler_state == nullptr) return fail("%s", "null grad / scaler_state");
+  return run_reduce(s, B, workspace, grad, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 0, nullptr, cursor_dev, loss, loss_hist,
+                    stream, nullptr, 1.f, scaler_state);
 }
 
 int32_t dmf_grad_reduce_adam(const dmf_shape* s, int32_t B, const void* workspace, float* theta, float* m, float* v,
@@ -611,14 +714,20 @@ int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64
   return check(hipGetLastError(), "adam launch");
 }
 
-int32_t dmf_qua_loss(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
-                     const dmf_qua_params* prm, float grad_scale, float* loss, float* loss_hist, float* dlogits,
-                     void* stream) {
+int32_t dmf_qua_loss_scaled(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
+                            const dmf_qua_params* prm, float grad_scale, const float* scaler_state, float* loss,
+                            float* loss_hist, float* dlogits, void* stream) {
   if (logits == nullptr || labels == nullptr || prm == nullptr) return fail("%s", "null argument");
   if (bs <= 0 || K < 2 || K > KMAX) return fail("%s", "qua_loss: bs must be positive and 2 <= K <= DMF_KMAX");
   QuaArgs a{logits, bs, K, labels, cursor, prm->alpha, prm->beta, prm->gamma, prm->epsilon, prm->tao, grad_scale,
-            loss, loss_hist, dlogits};
+            loss, loss_hist, dlogits, scaler_state};
   return check(launch_qua_loss(a, static_cast<hipStream_t>(stream)), "qua_loss launch");
+}
+
+int32_t dmf_qua_loss(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
+                     const dmf_qua_params* prm, float grad_scale, float* loss, float* loss_hist, float* dlogits,
+                     void* stream) {
+  return dmf_qua_loss_scaled(logits, bs, K, labels, cursor, prm, grad_scale, nullptr, loss, loss_hist, dlogits, stream);
 }
 
 int32_t dmf_pair_argmax(const float* logits, int32_t bs, int32_t K, int32_t* pred, void* stream) {

@@ -23,6 +23,7 @@ struct KArgs {
   const int32_t* labels;
   const float* dlogits;
   float loss_scale;
+  const float* scaler;  // nullable: device loss-scaler state, [0] multiplies loss_scale (dmf_train_fwd_bwd_scaled)
   float* logits;
   float* loss;
   int32_t* pred;
@@ -42,7 +43,8 @@ struct KArgs {
 int patch_shape_supported(const dmf_shape& s);
 hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
 // wave-per-channel-block kernel (dmf_patch_v2.hip): FWD / TRAIN / BWD of the shapes it is built for
-int patch_v2_supported(const dmf_shape& s, int mode);
+int patch_v2_supported(const dmf_shape& s, int mode, int half = 0);   // half: dmf_input.half (fp16 primary scene)
+const char* patch_v2_half_shape_list();
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
 // second half of the unit-gradient step: per patch dh, dz from dlogits; slab row of workgroup g = sum over its patches of
 // dz x unit row; ws_dh / ws_dl for the fc gradients
@@ -83,6 +85,7 @@ struct QuaArgs {
   const int32_t* labels; const int32_t* cursor;
   float alpha, beta, gamma, eps, tao, grad_scale;
   float* loss; float* loss_hist; float* dlogits;
+  const float* scaler;   // nullable: device loss-scaler state, [0] multiplies grad_scale
 };
 hipError_t launch_qua_loss(const QuaArgs& a, hipStream_t st);
 hipError_t launch_pair_argmax(const float* logits, int bs, int K, int32_t* pred, hipStream_t st);

@@ -706,7 +706,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
         if (MODE == MODE_TRAIN) {
           const float e = lane < K ? expf(lg - mx) : 0.f;
           const float se = wave_sum_dpp(e);
-          dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * a.loss_scale : 0.f;
+          const float ls = a.loss_scale * (a.scaler != nullptr ? a.scaler[0] : 1.f);
+          dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * ls : 0.f;
           const float lgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lg), label));
           loss_b = (mx + logf(se)) - lgt;
         } else {

@@ -117,9 +117,13 @@ constexpr int v2_pick_cpw(int F, int lpc) {
   return c;
 }
 
-template <class Sh, bool TR = true>
+// HF: the primary scene (and so the window image in LDS) holds IEEE fp16 — two bands per 32-bit word; spec_a then runs on
+// fp16 operands (window and weights, round-to-nearest-even) with fp32 accumulation.  Everything downstream is fp32.
+template <class Sh, bool TR = true, bool HF = false>
 struct V2 {
   static constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, G = Sh::G;
+  static constexpr int CW = HF ? Sh::C / 2 : Sh::C;     // 32-bit words per pixel
+  static constexpr int CgW = HF ? Cg / 2 : Cg;          // ... per band group
   // lanes per channel: P rows + at least one zero-padding lane, whole quads — except P = 16, where a channel is exactly one
   // 16-lane DPP row and the row shifts' own boundary zero-fill is the padding
   static constexpr bool ROWDPP = (P == 16);
@@ -133,7 +137,7 @@ struct V2 {
   // a 1-KiB gather piece is (mostly) 1 KiB of contiguous scene bytes; the paddings spread the row-lanes' ds_read_b128 over
   // the banks (v2_pick_layout)
   static constexpr int QC = Cg / 4;
-  static constexpr int LAYOUT = v2_pick_layout(Sh::C, P, Cg, LPC, CPW, Sh::M, NB);
+  static constexpr int LAYOUT = v2_pick_layout(CW, P, CgW, LPC, CPW, Sh::M, NB);
   static constexpr int CS = LAYOUT / 65536, RS = LAYOUT % 65536;
   static constexpr int XF = ((P * RS + 255) / 256) * 256;    // floats, whole pieces
   static constexpr int NPIECE = XF / 256;
@@ -159,8 +163,9 @@ struct V2 {
   static constexpr int oW2 = oSlab + NCOPY * Sh::SLAB;   // fc2.weight [K rounded up to 4][W2S]  (run-time K)
   static constexpr int FIXED = oW2;
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
+  // (a lane's 16-byte gather piece must not straddle a pixel — or, without pixel padding, a window row)
   static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && P <= 16 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
-                             P * RSP <= 2 * NT && NK <= 16;
+                             P * RSP <= 2 * NT && NK <= 16 && (CS == CW ? (P * CW) % 4 == 0 : CW % 4 == 0);
 };
 
 // LDS reads the compiler's waitcnt pass cannot see.  It orders EVERY LDS access it knows of behind all outstanding
@@ -198,6 +203,17 @@ __device__ __forceinline__ float wave_max_dpp(float v) {  // all 64 lanes, resul
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// acc + (float)half(x.lo | x.hi) * y in one instruction (v_fma_mix_f32; written out: in the unrolled gradient loops the
+// compiler converts first and multiplies after, twice the instructions)
+__device__ __forceinline__ float fma_mix_lo(float x2, float y, float acc) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(x2), "v"(y));
+  return acc;
+}
+__device__ __forceinline__ float fma_mix_hi(float x2, float y, float acc) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(x2), "v"(y));
+  return acc;
+}
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 __device__ __forceinline__ float relu_lim(float x, float lim) { return __builtin_amdgcn_fmed3f(x, 0.f, lim); }   // lim = +inf: ReLU; 0: 0
 
@@ -314,11 +330,11 @@ __device__ __forceinline__ void gather_piece(const float* base, int soff, int vo
 
 // INMODE: dmf_input.mode, compile time — with a run-time branch the waitcnt pass merges the two paths' states at the
 // join and waits vmcnt(0) there, i.e. for the whole window, before the aux phase.
-template <class Sh, int MODE, int INMODE>
+template <class Sh, int MODE, int INMODE, bool HF>
 __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   constexpr bool TR = (MODE != MODE_FWD);
   constexpr bool UNIT = (MODE == MODE_UNIT);           // forward + unit gradients per patch; loss and scaling happen elsewhere
-  using V = V2<Sh, TR>;
+  using V = V2<Sh, TR, HF>;
   constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, QC = V::QC;
   constexpr int LPC = V::LPC, CPW = V::CPW, NQ = V::NQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -380,8 +396,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   // This wave's share of the gather: pieces p = wave + k NW of the window image.  Lane l of piece p holds image floats
   // n = 256 p + 4 l .. + 3 = pixel n / CS, bands n % CS ..; its scene offset is ((row Wp + col) C + band) floats.
   auto issue_gather = [&](int x, int y) {
-    const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * Sh::C;
-    const int rowskip = (a.in.Wp - P) * Sh::C;               // floats between the end of a window row and the start of the next
+    const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * V::CW;     // (32-bit words: HF scenes hold two bands in each)
+    const int rowskip = (a.in.Wp - P) * V::CW;               // words between the end of a window row and the start of the next
     int l_ = lane;
     OPAQUE(l_);                                              // offsets are formed here, per patch: hoisted out of the patch loop
                                                              // they are spilled, and a scratch reload in front of a piece
@@ -391,15 +407,15 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       const int p = wave + k * V::NW;
       const int n = 256 * p + 4 * l_;
       int off;
-      if constexpr (V::CS == Sh::C) {                        // unpadded pixels: a window row is one contiguous run of the scene
+      if constexpr (V::CS == V::CW) {                        // unpadded pixels: a window row is one contiguous run of the scene
         const int pr = n / V::RS, within = n - pr * V::RS;
-        off = (within + pr * (rowskip + P * Sh::C)) * 4;
-        if (pr >= P || within >= P * Sh::C) off = -1;
+        off = (within + pr * (rowskip + P * V::CW)) * 4;
+        if (pr >= P || within >= P * V::CW) off = -1;
       } else {
         const int pr = n / V::RS, within = n - pr * V::RS;
         const int pc = within / V::CS, band = within - pc * V::CS;
-        off = ((pr * a.in.Wp + pc) * Sh::C + band) * 4;
-        if (pr >= P || pc >= P || band >= Sh::C) off = -1;
+        off = ((pr * a.in.Wp + pc) * V::CW + band) * 4;
+        if (pr >= P || pc >= P || band >= V::CW) off = -1;
       }
       if (p >= V::NPIECE) off = -1;
       gather_piece(base, 0, off, smem + V::oX + (p < V::NPIECE ? p : 0) * 256);
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     const int qd = r >> 2;                                                         \
     const bool lead = vch && (r & 3) == 0;                                         \
     const float lim = act ? INFINITY : 0.f;                                        \
-    const float* xr = smem + V::oX + rc * V::RS + (f / Sh::M) * Cg;                 \
+    const float* xr = smem + V::oX + rc * V::RS + (f / Sh::M) * V::CgW;             \
     float* sl = sSlab + qd * Sh::SLAB;                                             \
     (void)lead; (void)lim; (void)xr; (void)sl; (void)qd; (void)act
     VSTAMP(1);
@@ -555,7 +571,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         const float* __restrict__ srcA = a.in.a + (size_t)(boff + b) * Sh::C * P2;
         for (int e = tid; e < Sh::C * P2; e += V::NB * 64) {
           const int cb = e / P2, pix = e - cb * P2;
-          smem[V::oX + (pix / P) * V::RS + (pix % P) * V::CS + cb] = srcA[e];
+          if constexpr (HF) reinterpret_cast<_Float16*>(smem + V::oX + (pix / P) * V::RS + (pix % P) * V::CS)[cb] = (_Float16)srcA[e];
+          else smem[V::oX + (pix / P) * V::RS + (pix % P) * V::CS + cb] = srcA[e];
         }
       }
       VSTAMP(2);
@@ -641,7 +658,31 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         if (4 * q + 3 < P) pw[4 * q + 3] = v.w;
       }
       float y1a[P];
-      {   // spec_a: even / odd bands of the group in the two halves of a packed accumulator
+      if constexpr (HF) {   // spec_a on fp16 operands: two bands per word, v_dot2_f32_f16 (exact products, fp32 accumulate)
+        h2 w1h[Cg / 2];
+#pragma unroll
+        for (int q = 0; q < QC; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(sTh + Sh::oA1w + f * Cg + 4 * q);
+          w1h[2 * q] = (h2){(_Float16)v.x, (_Float16)v.y};
+          w1h[2 * q + 1] = (h2){(_Float16)v.z, (_Float16)v.w};
+        }
+        const float b1 = sTh[Sh::oA1b + f];
+        float ap[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) ap[c] = b1;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+          if (c % 3 == 0 && c > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < QC; ++q) {
+            const float2 xv = *reinterpret_cast<const float2*>(xr + c * V::CS + 2 * q);
+            ap[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xv.x), w1h[2 * q], ap[c], false);
+            ap[c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, xv.y), w1h[2 * q + 1], ap[c], false);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < P; ++c) y1a[c] = relu_lim(ap[c], lim);
+      } else {   // spec_a: even / odd bands of the group in the two halves of a packed accumulator
         v2f w1p[Cg / 2];
 #pragma unroll
         for (int q = 0; q < QC; ++q) {
@@ -694,7 +735,23 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
 
       // ------------------------------------------------------------------ unit gradients of spec_a from the still-resident window
       float acc[Cg], db1 = 0.f;
-      {
+      if constexpr (HF) {   // fp16 window x fp32 gradient, fp32 accumulate (v_fma_mix_f32)
+#pragma unroll
+        for (int j = 0; j < Cg; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+          if (c % 3 == 0 && c > 0) __builtin_amdgcn_sched_barrier(0);
+          db1 += dya[c];
+#pragma unroll
+          for (int q = 0; q < QC; ++q) {
+            const float2 xv = *reinterpret_cast<const float2*>(xr + c * V::CS + 2 * q);
+            acc[4 * q] = fma_mix_lo(xv.x, dya[c], acc[4 * q]);
+            acc[4 * q + 1] = fma_mix_hi(xv.x, dya[c], acc[4 * q + 1]);
+            acc[4 * q + 2] = fma_mix_lo(xv.y, dya[c], acc[4 * q + 2]);
+            acc[4 * q + 3] = fma_mix_hi(xv.y, dya[c], acc[4 * q + 3]);
+          }
+        }
+      } else {
         v2f gp[Cg / 2];
 #pragma unroll
         for (int j = 0; j < Cg / 2; ++j) gp[j] = (v2f){0.f, 0.f};
@@ -840,7 +897,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         if (MODE == MODE_TRAIN) {
           const float e = lane < K ? __expf(lg - mx) : 0.f;
           const float se = wave_sum_dpp(e);
-          dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * a.loss_scale : 0.f;
+          const float ls = a.loss_scale * (a.scaler != nullptr ? a.scaler[0] : 1.f);
+          dl = lane < K ? (e / se - (lane == label ? 1.f : 0.f)) * ls : 0.f;
           const float lgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lg), __builtin_amdgcn_readfirstlane(label)));
           loss_b = (mx + __logf(se)) - lgt;
         } else {
@@ -969,35 +1027,35 @@ __global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a)
 }
 
 // ---------------------------------------------------------------------------------------- launch
-template <class Sh, int MODE, int INMODE>
+template <class Sh, int MODE, int INMODE, bool HF>
 static hipError_t launch_v2_inst(const KArgs& a, int grid, int bytes, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_v2_kernel<Sh, MODE, INMODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_v2_kernel<Sh, MODE, INMODE, HF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((patch_v2_kernel<Sh, MODE, INMODE>), dim3(grid), dim3(V2<Sh>::NT), bytes, st, a);
+  hipLaunchKernelGGL((patch_v2_kernel<Sh, MODE, INMODE, HF>), dim3(grid), dim3(V2<Sh>::NT), bytes, st, a);
   return hipGetLastError();
 }
 
-template <class Sh>
+template <class Sh, bool HF>
 static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
   const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
   if (grid <= 0) return hipSuccess;
-  const int bytes = mode == MODE_FWD ? V2<Sh, false>::lds_bytes(a.K) : V2<Sh, true>::lds_bytes(a.K);
+  const int bytes = mode == MODE_FWD ? V2<Sh, false, HF>::lds_bytes(a.K) : V2<Sh, true, HF>::lds_bytes(a.K);
   if (bytes > 160 * 1024) return hipErrorInvalidValue;
   const bool gather = a.in.mode == 1;
   switch (mode) {
     case MODE_FWD:
-      return gather ? launch_v2_inst<Sh, MODE_FWD, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_FWD, 0>(a, grid, bytes, st);
+      return gather ? launch_v2_inst<Sh, MODE_FWD, 1, HF>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_FWD, 0, HF>(a, grid, bytes, st);
     case MODE_TRAIN:
-      return gather ? launch_v2_inst<Sh, MODE_TRAIN, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_TRAIN, 0>(a, grid, bytes, st);
+      return gather ? launch_v2_inst<Sh, MODE_TRAIN, 1, HF>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_TRAIN, 0, HF>(a, grid, bytes, st);
     case MODE_BWD:
-      return gather ? launch_v2_inst<Sh, MODE_BWD, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_BWD, 0>(a, grid, bytes, st);
+      return gather ? launch_v2_inst<Sh, MODE_BWD, 1, HF>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_BWD, 0, HF>(a, grid, bytes, st);
     case MODE_UNIT:
-      return gather ? launch_v2_inst<Sh, MODE_UNIT, 1>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_UNIT, 0>(a, grid, bytes, st);
+      return gather ? launch_v2_inst<Sh, MODE_UNIT, 1, HF>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_UNIT, 0, HF>(a, grid, bytes, st);
     default:
       return hipErrorInvalidValue;
   }
@@ -1018,6 +1076,12 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
   X(8, 1, 5, 1, 40, 2, 64)     /* small test scene, equal resolution */                                       \
   X(4, 1, 16, 1, 40, 1, 64)    /* stage 2 of the two-stage path: one 4-band stream + its band mean */          \
   X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */
+// ... and the rows that also get the fp16-scene kernels (dmf_input.half): a subset, each instance costs compile time
+#define DMF_V2_HALF_SHAPES(X)                                                                                 \
+  X(200, 1, 11, 1, 40, 10, 64)                                                                                \
+  X(224, 3, 11, 1, 32, 8, 64)                                                                                 \
+  X(8, 1, 5, 1, 40, 2, 64)                                                                                    \
+  X(4, 1, 16, 1, 40, 1, 64)
 
 template <class Sh>
 static bool v2_matches(const dmf_shape& s) {
@@ -1025,12 +1089,21 @@ static bool v2_matches(const dmf_shape& s) {
   return s.C == Sh::C && s.C2 == Sh::C2 && s.P == Sh::P && s.S == Sh::S && s.F == Sh::F && s.G == Sh::G && s.H == Sh::H;
 }
 
-template <class Sh>
-static bool v2_fits(const dmf_shape& s) { return v2_matches<Sh>(s) && V2<Sh, true>::lds_bytes(s.K) <= 160 * 1024; }
+template <class Sh, bool HF = false>
+static bool v2_fits(const dmf_shape& s) {
+  static_assert(V2<Sh, true, HF>::OK, "shape outside the v2 kernel's geometry");
+  return v2_matches<Sh>(s) && V2<Sh, true, HF>::lds_bytes(s.K) <= 160 * 1024;
+}
 
-int patch_v2_supported(const dmf_shape& s, int mode) {
+int patch_v2_supported(const dmf_shape& s, int mode, int half) {
   if (mode != MODE_FWD && mode != MODE_TRAIN && mode != MODE_BWD && mode != MODE_UNIT) return 0;
   if (s.K < 1 || s.K > KMAX || s.attention) return 0;
+  if (half) {
+#define X(C, C2, P, S, F, G, H) if (v2_fits<Shape<C, C2, P, S, F, G, H>, true>(s)) return 1;
+    DMF_V2_HALF_SHAPES(X)
+#undef X
+    return 0;
+  }
 #define X(C, C2, P, S, F, G, H) if (v2_fits<Shape<C, C2, P, S, F, G, H>>(s)) return 1;
   DMF_V2_SHAPES(X)
 #undef X
@@ -1049,10 +1122,26 @@ const char* patch_v2_shape_list() {
 }
 
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
-#define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2<Shape<C, C2, P, S, F, G, H>>(mode, a, st);
+  if (a.in.half) {
+#define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2<Shape<C, C2, P, S, F, G, H>, true>(mode, a, st);
+    DMF_V2_HALF_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+  }
+#define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2<Shape<C, C2, P, S, F, G, H>, false>(mode, a, st);
   DMF_V2_SHAPES(X)
 #undef X
   return hipErrorInvalidValue;
+}
+
+const char* patch_v2_half_shape_list() {
+#define STR2(x) #x
+#define STR(x) STR2(x)
+#define X(C, C2, P, S, F, G, H) " " STR(C) "/" STR(C2) "/" STR(P) "/" STR(S) "/" STR(F) "/" STR(G)
+  return DMF_V2_HALF_SHAPES(X);
+#undef X
+#undef STR
+#undef STR2
 }
 
 hipError_t patch_v2_unit_backward(const dmf_shape& s, const UnitBwdArgs& a, hipStream_t st) {

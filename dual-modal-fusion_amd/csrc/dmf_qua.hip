@@ -199,7 +199,8 @@ __global__ __launch_bounds__(QT) void qua_loss_kernel(const QuaArgs a, const int
       float* g = a.dlogits + ((size_t)st * bs + t0 + i) * K;
       float ip = 0.f;
       for (int k = 0; k < K; ++k) { const float d = dprob(k); g[k] = d; ip += d * y[k]; }     // (row parked in its output)
-      for (int k = 0; k < K; ++k) g[k] = a.grad_scale * y[k] * (g[k] - ip);
+      const float gs = a.grad_scale * (a.scaler != nullptr ? a.scaler[0] : 1.f);
+      for (int k = 0; k < K; ++k) g[k] = gs * y[k] * (g[k] - ip);
     }
   }
 }

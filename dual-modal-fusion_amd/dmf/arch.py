@@ -3,7 +3,7 @@
 Reference keys consumed: `patch_size`, `Categories_Number`, `DATA_DICT[data_city].size[2]`
 (config.yml:27-28,77-80), `trans.embed_dim` / `trans.num_head` (config.yml:66-73; consumed by nothing in the
 reference).  Keys this build adds: `scale` (aux/primary resolution ratio; the reference hard-codes 4,
-train/dataset.py:166), `aux_bands`, `gmf.{width,groups,hidden,pool_sigma,attention,single_input}`.
+train/dataset.py:166), `aux_bands`, `gmf.{width,groups,hidden,pool_sigma,attention,single_input,half}`.
 """
 import math
 
@@ -37,6 +37,7 @@ def arch_from_cfg(cfg):
         K=int(cfg['Categories_Number']), F=width, G=int(groups), H=int(gmf.get('hidden', 64)),
         sigma=float(gmf.get('pool_sigma', 2.5)), attention=int(gmf.get('attention', 0)),
         heads=int(trans.get('num_head', 3)), E=int(trans.get('embed_dim', 96)),
+        half=int(gmf.get('half', 0)),                # fp16 primary scene / patches, fp16 operands in spec_a (include/dmf.h: dmf_input.half)
     )
 
 

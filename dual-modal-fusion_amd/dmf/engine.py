@@ -22,23 +22,50 @@ from . import lib
 
 
 class Scene:
-    """Padded, normalised scenes resident in HBM: A [Hp, Wp, C], B [HpB, WpB, C2] (pixel-major, fp32)."""
+    """Padded, normalised scenes resident in HBM: A [Hp, Wp, C], B [HpB, WpB, C2] (pixel-major, fp32).
+    half: A is kept as IEEE fp16 (`gmf.half`; numpy's float32 -> float16 rounds to nearest even, as the oracle does)."""
 
-    def __init__(self, primary, aux, device):
+    def __init__(self, primary, aux, device, half=False):
         A = np.ascontiguousarray(primary, dtype=np.float32)
         Bm = np.ascontiguousarray(aux, dtype=np.float32)
         if Bm.ndim == 2:
             Bm = Bm[:, :, None]
-        self.A = torch.from_numpy(A).to(device)
+        self.half = bool(half)
+        self.A = torch.from_numpy(A.astype(np.float16) if half else A).to(device)
         self.B = torch.from_numpy(Bm).to(device)
         self.device = torch.device(device)
 
 
+class LossScaler:
+    """Device-resident dynamic loss scale — the role of `torch.cuda.amp.GradScaler` (tostagesolver.py:83-84 builds two
+    with torch's defaults; :98 / :119 scale -> step -> update).  Same defaults and update rule; the state never visits
+    the host, so a captured graph carries it."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.state = torch.zeros(lib.SCALER_FLOATS, device=device)
+        lib.scaler_init(self.state, float(init_scale))
+
+    def get_scale(self):
+        return float(self.state[0].item())
+
+    def skipped_steps(self):
+        return int(self.state[3].item())
+
+    def hparams(self):
+        return (self.growth_factor, self.backoff_factor, self.growth_interval)
+
+
 class TrainEngine:
-    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm=None):
+    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm=None, scaler=None):
         self.net, self.scene, self.B = net, scene, int(batch)
         self.shape = net.shape
         lib.shape_supported(self.shape)
+        if getattr(scene, 'half', False):
+            lib.require_half(self.shape)
+        self.scaler = scaler
+        if scaler is not None and (comm is not None or self.shape.attention):
+            raise lib.DmfError('loss scaling: late-fusion net, single GPU or RCCL data parallel (not the xgmi exchange)')
         self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         dev = scene.device
         self.theta = net.flat_parameters()
@@ -93,8 +120,29 @@ class TrainEngine:
         self.step_count += 1
         theta = self.theta
         nB = inp.B
-        if self.comm is not None and dev_step is None:   # the exchange numbers its rounds by the device step count
-            dev_step = self.dev_step
+        if (self.comm is not None or self.scaler is not None) and dev_step is None:
+            dev_step = self.dev_step                     # the exchange numbers its rounds by the device step count; with a
+                                                         # loss scaler skipped steps make the device count the only true one
+        if self.scaler is not None:
+            # scaler.scale(loss).backward() -> [all-reduce] -> scaler.unscale_ + scaler.step(opt) + scaler.update()
+            sc = self.scaler
+            lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
+                              adam_step_dev=dev_step, scaler_state=sc.state)
+            if self.world == 1:                          # three launches: patch kernel, reduce (+ unscale + check), Adam-or-skip
+                lib.grad_reduce_scaled(self.shape, nB, self.ws, self.grad, sc.state, cursor_dev=dev_cursor,
+                                       loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
+                lib.unscale_adam(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, sc.state,
+                                 sc.growth_factor, sc.backoff_factor, sc.growth_interval, dev_step, unscaled=True)
+                return
+            import torch.distributed as dist
+            lib.grad_reduce(self.shape, nB, self.ws, self.grad)
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)     # the check must see the SUM: after it
+            if loss_hist is not None:
+                loss_hist.scatter_(0, dev_cursor.long(), self.loss[:nB].mean().reshape(1))
+            lib.unscale_adam(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, sc.state,
+                             sc.growth_factor, sc.backoff_factor, sc.growth_interval, dev_step,
+                             grad_scale=1.0 / self.world, cursor_dev=dev_cursor)
+            return
         if self.shape.attention:
             lib.train_attn_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, None, 1.0 / nB, self.logits, self.loss,
                                    self.ws, self.attn_ws, adam_step_dev=dev_step)
@@ -139,7 +187,8 @@ class TrainEngine:
             self.graph = None
         self.dev_cursor.zero_()
         self.host_cursor = 0
-        self.dev_step.fill_(self.step_count)
+        if self.scaler is None:                    # (with a scaler the device count is authoritative: skipped steps)
+            self.dev_step.fill_(self.step_count)
         self.plan_steps = n
         return n
 
@@ -178,6 +227,8 @@ class TrainEngine:
         # hipFuncSetAttribute is not capturable, so every kernel must have been launched once before the capture:
         # run one step eagerly, then put back the exact pre-step state (capture itself executes nothing).
         state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
+        if self.scaler is not None:
+            state = state + (self.scaler.state,)
         count0 = self.step_count
         saved = [t.clone() for t in state]
         self._plan_step()
@@ -209,7 +260,7 @@ class TrainEngine:
         self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
 
     def _hparams(self):
-        return (self.lr, self.b1, self.b2, self.eps)
+        return (self.lr, self.b1, self.b2, self.eps) + (self.scaler.hparams() if self.scaler is not None else ())
 
     def mean_losses(self):
         """Per-step mean CE of the plan steps run so far (one D2H copy)."""
@@ -306,13 +357,16 @@ class QuaScene:
     auxiliary modality).  Stream k's patch at pixel (x, y) is the tall scene's patch at (x + k*Hp, y); a window
     never crosses into the next stream because every stream carries its own bottom padding."""
 
-    def __init__(self, scenes, device):
+    def __init__(self, scenes, device, half=False):
         if len(scenes) != 4 or any(s.shape != scenes[0].shape for s in scenes):
             raise lib.DmfError('stage 2 wants four scenes of one shape')
         self.Hp = int(scenes[0].shape[0])
         tall = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.float32) for s in scenes], axis=0))
         self.A = torch.from_numpy(tall).to(device)
-        self.B = lib.band_mean_scene(self.A)
+        self.B = lib.band_mean_scene(self.A)          # (of the fp32 bands: the aux modality stays fp32)
+        self.half = bool(half)
+        if half:                                      # `gmf.half`: the primary scene is kept as fp16 (round to nearest even)
+            self.A = self.A.to(torch.float16)
         self.device = torch.device(device)
 
     def stack_xy(self, xy, streams=4):
@@ -338,13 +392,18 @@ class QuaTrainEngine:
     Data parallel (process_group): every rank takes its shard of each batch; the logits of all ranks are gathered so that
     the batch-coupled loss is the GLOBAL batch's, the flat gradient is all-reduced (sum) and ADAM runs with 1/world."""
 
-    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, scaler=None):
         if not net.arch.get('single_input'):
             raise lib.DmfError('stage 2 needs the single-input net (cfg["gmf"]["single_input"] = 1)')
         self.net, self.scene, self.bs = net, scene, int(bs)
         self.shape = net.shape
         lib.shape_supported(self.shape)
         self.unit = lib.unit_supported(self.shape)
+        if getattr(scene, 'half', False):
+            lib.require_half(self.shape)
+        self.scaler = scaler
+        if scaler is not None and (process_group is not None or not self.unit):
+            raise lib.DmfError('loss scaling in stage 2: unit-gradient step on one GPU')
         self.params = lib.qua_params(dqtl)
         self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         dev = scene.device
@@ -373,6 +432,19 @@ class QuaTrainEngine:
     def _step(self, inp, bs, labels, cursor, loss_hist, dev_step=None):
         self.step_count += 1
         theta = self.theta
+        if self.scaler is not None:
+            # scaler.scale(loss).backward(); scaler.step(opt); scaler.update()  (tostagesolver.py:98,119 do this for the
+            # stage-1 pair; here it wraps the stage-2 step)
+            sc = self.scaler
+            dev_step = self.dev_step if dev_step is None else dev_step
+            lib.forward_unit(self.shape, inp, theta, self.net.pool_w, self.logits, self.ws, adam_step_dev=dev_step)
+            lib.qua_loss(self.logits[:4 * bs], bs, labels, self.params, loss=self.loss, dlogits=self.dlogits[:4 * bs],
+                         cursor=cursor, loss_hist=loss_hist, scaler_state=sc.state)
+            lib.backward_unit(self.shape, 4 * bs, theta, self.dlogits, self.ws)
+            lib.grad_reduce_scaled(self.shape, 4 * bs, self.ws, self.grad, sc.state, cursor_dev=cursor)
+            lib.unscale_adam(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, sc.state,
+                             sc.growth_factor, sc.backoff_factor, sc.growth_interval, dev_step, unscaled=True)
+            return
         if self.unit:
             lib.forward_unit(self.shape, inp, theta, self.net.pool_w, self.logits, self.ws, adam_step_dev=dev_step)
         else:
@@ -471,7 +543,8 @@ class QuaTrainEngine:
         self.loss_hist.zero_()
         self.dev_cursor.zero_()
         self.host_cursor = 0
-        self.dev_step.fill_(self.step_count)
+        if self.scaler is None:
+            self.dev_step.fill_(self.step_count)
         self.plan_steps = n
         return n
 
@@ -486,6 +559,8 @@ class QuaTrainEngine:
         if not self.unit or self.world > 1:
             raise lib.DmfError('graph replay needs the unit-gradient step on one GPU')
         state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
+        if self.scaler is not None:
+            state = state + (self.scaler.state,)
         count0 = self.step_count
         saved = [t.clone() for t in state]
         self._plan_step()
@@ -531,8 +606,8 @@ class QuaTrainEngine:
     def dominant_name(self):
         a = self.net.arch
         if self.unit:
-            return 'dmf::patch_v2_kernel<Shape<%d,%d,%d,1,%d,..>, MODE_UNIT> (dmf_forward_unit: forward + unit gradients of the 4*bs stacked patches)' % (
-                a['C'], a['C2'], a['P'], a['F'])
+            return 'dmf::patch_v2_kernel<Shape<%d,%d,%d,1,%d,..>, MODE_UNIT%s> (dmf_forward_unit: forward + unit gradients of the 4*bs stacked patches)' % (
+                a['C'], a['C2'], a['P'], a['F'], ', fp16 scene' if getattr(self.scene, 'half', False) else '')
         return 'dmf::patch_kernel<ShapeQua, MODE_BWD> (dmf_backward_dlogits: forward recompute + backward of the 4*bs stacked patches)'
 
 

@@ -32,7 +32,8 @@ class QuaParams(C.Structure):
 
 class Input(C.Structure):
     _fields_ = [('mode', C.c_int32), ('B', C.c_int32), ('a', C.c_void_p), ('b', C.c_void_p), ('sceneA', C.c_void_p),
-                ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32), ('cursor', C.c_void_p)]
+                ('sceneB', C.c_void_p), ('xy', C.c_void_p), ('Wp', C.c_int32), ('WpB', C.c_int32), ('cursor', C.c_void_p),
+                ('half', C.c_int32), ('reserved', C.c_int32)]
 
 
 def _load():
@@ -53,6 +54,12 @@ def _load():
         'dmf_attn_workspace_bytes': (i64, [SP, i32]),
         'dmf_forward_attn': (i32, [SP, IP, vp, vp, vp, vp, vp, vp]),
         'dmf_train_fwd_bwd': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp]),
+        'dmf_train_fwd_bwd_scaled': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
+        'dmf_half_supported': (i32, [SP]),
+        'dmf_scaler_init': (i32, [vp, f32, vp]),
+        'dmf_unscale_adam': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, i32, vp, vp, vp]),
+        'dmf_grad_reduce_scaled': (i32, [SP, i32, vp, vp, vp, vp, vp, vp, vp]),
+        'dmf_qua_loss_scaled': (i32, [vp, i32, i32, vp, vp, C.POINTER(QuaParams), f32, vp, vp, vp, vp, vp]),
         'dmf_attn_train_workspace_bytes': (i64, [SP, i32]),
         'dmf_train_attn_fwd_bwd': (i32, [SP, IP, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
         'dmf_backward_dlogits': (i32, [SP, IP, vp, vp, vp, vp, vp]),
@@ -116,6 +123,37 @@ def unit_supported(shape):
     return _lib.dmf_unit_supported(C.byref(shape)) == 0
 
 
+def half_supported(shape):
+    """True if the fp16-scene kernels (Input.half) exist for this shape."""
+    return _lib.dmf_half_supported(C.byref(shape)) == 0
+
+
+def require_half(shape):
+    check(_lib.dmf_half_supported(C.byref(shape)))
+
+
+SCALER_FLOATS = 8
+
+
+def scaler_init(state, init_scale):
+    _dev(state, torch.float32, 'scaler state')
+    if state.numel() < SCALER_FLOATS:
+        raise DmfError('scaler state needs %d floats' % SCALER_FLOATS)
+    check(_lib.dmf_scaler_init(_ptr(state), init_scale, _stream()))
+
+
+def unscale_adam(theta, grad, m, v, lr, b1, b2, eps, scaler_state, growth_factor, backoff_factor, growth_interval,
+                 adam_step_dev, grad_scale=1.0, cursor_dev=None, unscaled=False):
+    check(_lib.dmf_unscale_adam(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), lr, b1, b2, eps, grad_scale,
+                                _ptr(scaler_state), growth_factor, backoff_factor, growth_interval, int(bool(unscaled)),
+                                _ptr(adam_step_dev), _ptr(cursor_dev), _stream()))
+
+
+def grad_reduce_scaled(shape, B, ws, grad, scaler_state, cursor_dev=None, loss=None, loss_hist=None):
+    check(_lib.dmf_grad_reduce_scaled(C.byref(shape), B, _ptr(ws), _ptr(grad), _ptr(scaler_state), _ptr(cursor_dev),
+                                      _ptr(loss), _ptr(loss_hist), _stream()))
+
+
 def forward_unit(shape, inp, theta, pool_w, logits, ws, adam_step_dev=None):
     check(_lib.dmf_forward_unit(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(logits), _ptr(ws),
                                 _ptr(adam_step_dev), _stream()))
@@ -152,28 +190,32 @@ def _dev(t, dtype, name):
     return t
 
 
-def input_patches(shape, a, b):
-    """mode 0: the reference dataloader's tensors, a [B,C,P,P], b [B,C2,SP,SP] (dataset.py:168-185)."""
+def input_patches(shape, a, b, half=False):
+    """mode 0: the reference dataloader's tensors, a [B,C,P,P], b [B,C2,SP,SP] (dataset.py:168-185).
+    half: `a` is rounded to fp16 as the kernel stages it (the arithmetic of an fp16 scene)."""
     _dev(a, torch.float32, 'a'); _dev(b, torch.float32, 'b')
     B = a.shape[0]
     SP = shape.S * shape.P
     if tuple(a.shape) != (B, shape.C, shape.P, shape.P) or tuple(b.shape) != (B, shape.C2, SP, SP):
         raise DmfError('patch tensors %s / %s do not match shape C=%d P=%d C2=%d S=%d' %
                        (tuple(a.shape), tuple(b.shape), shape.C, shape.P, shape.C2, shape.S))
-    return Input(mode=0, B=B, a=a.data_ptr(), b=b.data_ptr(), sceneA=None, sceneB=None, xy=None, Wp=0, WpB=0, cursor=None)
+    return Input(mode=0, B=B, a=a.data_ptr(), b=b.data_ptr(), sceneA=None, sceneB=None, xy=None, Wp=0, WpB=0, cursor=None,
+                 half=int(bool(half)), reserved=0)
 
 
 def input_gather(shape, sceneA, sceneB, xy, B=None, cursor=None):
     """mode 1: sceneA [Hp,Wp,C], sceneB [HpB,WpB,C2] resident padded scenes, xy [B,2] int32 top-left pixels.
-    With `cursor` (device int32[1]) xy is a whole epoch plan [n_steps*B, 2] and `B` the batch size."""
-    _dev(sceneA, torch.float32, 'sceneA'); _dev(sceneB, torch.float32, 'sceneB'); _dev(xy, torch.int32, 'xy')
+    With `cursor` (device int32[1]) xy is a whole epoch plan [n_steps*B, 2] and `B` the batch size.
+    sceneA may be fp16 (Input.half: shapes of half_supported())."""
+    half = sceneA.dtype == torch.float16
+    _dev(sceneA, torch.float16 if half else torch.float32, 'sceneA'); _dev(sceneB, torch.float32, 'sceneB'); _dev(xy, torch.int32, 'xy')
     if sceneA.dim() != 3 or sceneA.shape[2] != shape.C or sceneB.dim() != 3 or sceneB.shape[2] != shape.C2:
         raise DmfError('scene tensors must be [Hp,Wp,C] and [HpB,WpB,C2]')
     if xy.dim() != 2 or xy.shape[1] != 2:
         raise DmfError('xy must be [B,2]')
     return Input(mode=1, B=xy.shape[0] if B is None else B, a=None, b=None, sceneA=sceneA.data_ptr(),
                  sceneB=sceneB.data_ptr(), xy=xy.data_ptr(), Wp=sceneA.shape[1], WpB=sceneB.shape[1],
-                 cursor=None if cursor is None else cursor.data_ptr())
+                 cursor=None if cursor is None else cursor.data_ptr(), half=int(half), reserved=0)
 
 
 def check_xy_bounds(shape, sceneA, sceneB, xy_host):
@@ -199,7 +241,12 @@ def forward_attn(shape, inp, theta, pool_w, ws, logits, pred=None):
                                 _ptr(pred), _stream()))
 
 
-def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, adam_step_dev=None):
+def train_fwd_bwd(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, adam_step_dev=None, scaler_state=None):
+    if scaler_state is not None:
+        check(_lib.dmf_train_fwd_bwd_scaled(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels),
+                                            C.c_float(loss_scale), _ptr(scaler_state), _ptr(logits), _ptr(loss), _ptr(ws),
+                                            _ptr(adam_step_dev), _stream()))
+        return
     check(_lib.dmf_train_fwd_bwd(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels),
                                  C.c_float(loss_scale), _ptr(logits), _ptr(loss), _ptr(ws), _ptr(adam_step_dev), _stream()))
 
@@ -293,7 +340,8 @@ def qua_params(dqtl):
     return QuaParams(alpha=dqtl['alpha'], beta=dqtl['beta'], gamma=dqtl['gamma'], epsilon=dqtl['epsilon'], tao=dqtl['tao'])
 
 
-def qua_loss(logits, bs, labels, params, loss=None, dlogits=None, grad_scale=1.0, cursor=None, loss_hist=None):
+def qua_loss(logits, bs, labels, params, loss=None, dlogits=None, grad_scale=1.0, cursor=None, loss_hist=None,
+             scaler_state=None):
     _dev(logits, torch.float32, 'logits'); _dev(labels, torch.int32, 'labels')
     K = logits.shape[1]
     if logits.dim() != 2 or logits.shape[0] != 4 * bs:
@@ -304,8 +352,8 @@ def qua_loss(logits, bs, labels, params, loss=None, dlogits=None, grad_scale=1.0
         _dev(dlogits, torch.float32, 'dlogits')
         if dlogits.shape != logits.shape:
             raise DmfError('dlogits must have the shape of logits')
-    check(_lib.dmf_qua_loss(_ptr(logits), bs, K, _ptr(labels), _ptr(cursor), C.byref(params), grad_scale, _ptr(loss),
-                            _ptr(loss_hist), _ptr(dlogits), _stream()))
+    check(_lib.dmf_qua_loss_scaled(_ptr(logits), bs, K, _ptr(labels), _ptr(cursor), C.byref(params), grad_scale,
+                                   _ptr(scaler_state), _ptr(loss), _ptr(loss_hist), _ptr(dlogits), _stream()))
 
 
 def pair_argmax(logits, bs, pred):

@@ -27,7 +27,7 @@ class _GmfFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, a, b, theta):
-        inp = lib.input_patches(net.shape, a, b)
+        inp = lib.input_patches(net.shape, a, b, half=net.arch.get('half', 0))
         logits = torch.empty(a.shape[0], net.arch['K'], device=a.device, dtype=torch.float32)
         lib.forward(net.shape, inp, theta, net.pool_w, logits)
         ctx.net = net
@@ -38,7 +38,7 @@ class _GmfFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         net = ctx.net
         a, b, theta = ctx.saved_tensors
-        inp = lib.input_patches(net.shape, a, b)
+        inp = lib.input_patches(net.shape, a, b, half=net.arch.get('half', 0))
         B = a.shape[0]
         ws = net.workspace(B)
         lib.backward_dlogits(net.shape, inp, theta, net.pool_w, dlogits.contiguous().float(), ws)
@@ -53,7 +53,7 @@ class _GmfAttnFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, a, b, theta):
-        inp = lib.input_patches(net.shape, a, b)
+        inp = lib.input_patches(net.shape, a, b, half=net.arch.get('half', 0))
         B = a.shape[0]
         logits = torch.empty(B, net.arch['K'], device=a.device, dtype=torch.float32)
         ws = torch.empty(lib.attn_workspace_bytes(net.shape, B), device=a.device, dtype=torch.uint8)
@@ -66,7 +66,7 @@ class _GmfAttnFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         net = ctx.net
         a, b, theta = ctx.saved_tensors
-        inp = lib.input_patches(net.shape, a, b)
+        inp = lib.input_patches(net.shape, a, b, half=net.arch.get('half', 0))
         B = a.shape[0]
         ws = net.workspace(B)
         attn_ws = torch.empty(lib.attn_train_workspace_bytes(net.shape, B), device=a.device, dtype=torch.uint8)
@@ -160,7 +160,7 @@ class Net(nn.Module):
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 theta_g = torch.cat([p.reshape(-1) for p in self._named()])
                 return _GmfAttnFunction.apply(self, a, b, theta_g)
-            inp = lib.input_patches(self.shape, a, b)
+            inp = lib.input_patches(self.shape, a, b, half=self.arch.get('half', 0))
             B = a.shape[0]
             logits = torch.empty(B, self.arch['K'], device=a.device, dtype=torch.float32)
             ws = torch.empty(lib.attn_workspace_bytes(self.shape, B), device=a.device, dtype=torch.uint8)
@@ -170,7 +170,7 @@ class Net(nn.Module):
             # route the flat gradient back to the individual parameters through a differentiable cat
             theta_g = torch.cat([p.reshape(-1) for p in self._named()])
             return _GmfFunction.apply(self, a, b, theta_g)
-        inp = lib.input_patches(self.shape, a, b)
+        inp = lib.input_patches(self.shape, a, b, half=self.arch.get('half', 0))
         logits = torch.empty(a.shape[0], self.arch['K'], device=a.device, dtype=torch.float32)
         lib.forward(self.shape, inp, theta, self.pool_w, logits)
         return logits

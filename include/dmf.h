@@ -58,6 +58,12 @@ typedef struct dmf_input {
      when non-NULL, patch b reads xy[(*cursor)*B + b] and labels[(*cursor)*B + b].  Lets a captured
      hipGraph of many steps be replayed without host-side pointer updates. */
   const int32_t* cursor;
+  /* mode 1: sceneA holds IEEE fp16 [Hp, Wp, C] instead of fp32 (half the gather bytes).  The first 1x1 conv then runs on
+     fp16 operands (window and weights rounded to nearest even) with fp32 accumulation; everything behind it, gradients
+     included, stays fp32 (oracle: cfg['gmf']['half'] = 1).  mode 0 with half != 0: the fp32 patches `a` are rounded to
+     fp16 as they are staged.  Shapes: dmf_half_supported. */
+  int32_t half;
+  int32_t reserved;
 } dmf_input;
 
 int32_t dmf_version(void);
@@ -134,6 +140,38 @@ int32_t dmf_forward_unit(const dmf_shape* shape, const dmf_input* in, const floa
 int32_t dmf_backward_unit(const dmf_shape* shape, int32_t B, const float* theta, const float* dlogits, void* workspace,
                           void* stream);
 
+/* 0 if the fp16-scene kernels (dmf_input.half) exist for this shape. */
+int32_t dmf_half_supported(const dmf_shape* shape);
+
+/* ---- dynamic loss scaling: the role of `torch.cuda.amp.GradScaler` (tostagesolver.py:83-84 creates two, :98 / :119
+ * `scaler.scale(loss).backward(); scaler.step(opt); scaler.update()`), device-resident so that a captured graph can
+ * carry it.  state = DMF_SCALER_FLOATS floats on the device: [0] scale, [1] growth tracker, [2] found_inf of the step in
+ * flight, [3] number of skipped steps so far, [4..] internal.
+ *   dmf_scaler_init            state <- (init_scale, 0, 0, 0)                       GradScaler(init_scale=65536.)
+ *   dmf_train_fwd_bwd_scaled   dmf_train_fwd_bwd with dL/dlogits multiplied by loss_scale * state[0]   scaler.scale(loss)
+ *   dmf_qua_loss_scaled        the same for the stage-2 loss kernel (dlogits multiplied by grad_scale * state[0])
+ *   dmf_grad_reduce_scaled     dmf_grad_reduce with the unscale (grad = sum / state[0]) and the non-finite check folded in,
+ *                              plus the bookkeeping of dmf_grad_reduce_adam (loss_hist[cursor] = mean loss, cursor += 1);
+ *                              follow with dmf_unscale_adam(unscaled = 1).  Single GPU: data parallel must check AFTER
+ *                              the all-reduce (dmf_grad_reduce, all-reduce, dmf_unscale_adam(unscaled = 0))
+ *   dmf_unscale_adam           grad *= grad_scale / state[0] (skipped when unscaled != 0);
+ *                              any non-finite element -> the WHOLE step is skipped (no Adam state
+ *                              change, adam_step_dev taken back), scale *= backoff_factor, tracker = 0; else Adam as
+ *                              dmf_adam_step and tracker += 1, at growth_interval: scale *= growth_factor, tracker = 0
+ *                              (scaler.unscale_ + scaler.step + scaler.update).  grad is the flat gradient of
+ *                              dmf_grad_reduce (after the all-reduce when data parallel); adam_step_dev is required. */
+#define DMF_SCALER_FLOATS 8
+int32_t dmf_scaler_init(float* state, float init_scale, void* stream);
+int32_t dmf_train_fwd_bwd_scaled(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                                 const int32_t* labels, float loss_scale, const float* scaler_state,
+                                 float* logits, float* loss, void* workspace, int32_t* adam_step_dev, void* stream);
+int32_t dmf_unscale_adam(float* theta, float* grad, float* m, float* v, int64_t n,
+                         float lr, float beta1, float beta2, float eps, float grad_scale,
+                         float* scaler_state, float growth_factor, float backoff_factor, int32_t growth_interval,
+                         int32_t unscaled, int32_t* adam_step_dev, int32_t* cursor_dev, void* stream);
+int32_t dmf_grad_reduce_scaled(const dmf_shape* shape, int32_t B, const void* workspace, float* grad, float* scaler_state,
+                               int32_t* cursor_dev, const float* loss, float* loss_hist, void* stream);
+
 /* Backward for a caller-supplied dL/dlogits [B, K] (the autograd path: torch computes the loss). */
 int32_t dmf_backward_dlogits(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                              const float* dlogits, void* workspace, void* stream);
@@ -171,6 +209,9 @@ typedef struct dmf_qua_params { float alpha, beta, gamma, epsilon, tao; } dmf_qu
 int32_t dmf_qua_loss(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
                      const dmf_qua_params* params, float grad_scale, float* loss, float* loss_hist, float* dlogits,
                      void* stream);
+int32_t dmf_qua_loss_scaled(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,
+                            const dmf_qua_params* params, float grad_scale, const float* scaler_state,
+                            float* loss, float* loss_hist, float* dlogits, void* stream);
 /* Replaces `(output[:bs] + output[bs:2*bs]).softmax(dim=-1).data.max(1)[1]` (tostagesolver.py:337,366,378). */
 int32_t dmf_pair_argmax(const float* logits, int32_t bs, int32_t K, int32_t* pred, void* stream);
 /* Auxiliary input of the single-stream net: per-pixel mean over bands, ((x0+x1)+x2)+... then / C.

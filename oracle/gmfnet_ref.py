@@ -58,6 +58,7 @@ def arch_from_cfg(cfg):
         K=int(cfg['Categories_Number']), F=width, G=int(groups), H=int(gmf.get('hidden', 64)),
         sigma=float(gmf.get('pool_sigma', 2.5)), attention=int(gmf.get('attention', 0)),
         heads=heads, E=embed, mfma_bf16=int(gmf.get('mfma_bf16', 1)),
+        half=int(gmf.get('half', 0)),
     )
 
 
@@ -124,7 +125,15 @@ class Net(nn.Module):
 
     # -- pieces, exposed so tests can probe intermediate tensors ------------------------------
     def branches(self, a, b):
-        ya = F_.relu(self.spat_a(F_.relu(self.spec_a(a))))
+        if self.arch.get('half'):
+            # gmf.half: the primary modality is STORED as fp16 and spec_a runs on fp16 operands — input and weight rounded to
+            # nearest even, exact products, fp32 accumulation (what v_dot2_f32_f16 / v_fma_mix_f32 do in the HIP kernel).
+            # The roundings have no gradient of their own (straight through): the fp32 master weight gets the gradient of
+            # its rounded copy, as under torch.autocast (tostagesolver.py:86-178 runs stage 1 that way).
+            y1 = F_.conv2d(_ste_f16(a), _ste_f16(self.spec_a.weight), self.spec_a.bias, groups=self.spec_a.groups)
+            ya = F_.relu(self.spat_a(F_.relu(y1)))
+        else:
+            ya = F_.relu(self.spat_a(F_.relu(self.spec_a(a))))
         yb = F_.relu(self.spat_b(F_.relu(self.lift_b(b))))
         return ya, yb
 
@@ -191,6 +200,20 @@ class _SteBf16(torch.autograd.Function):
 
 def _ste_bf16(x):
     return _SteBf16.apply(x)
+
+
+class _SteF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.float16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _ste_f16(x):
+    return _SteF16.apply(x)
 
 
 def adam_step_ref(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
