@@ -154,13 +154,24 @@ struct V2 {
   static constexpr int NZB = TR ? 1 : 2;
   static constexpr int oZP = oZ + NZB * ZS;           // per conv wave: the quad partials of its channels' pooled features [NB][ZPW]
   static constexpr int ZPW = ((2 * CPW * NQ + 15) / 16) * 16;
-  static constexpr int oHv = oZP + NB * ZPW;          // h [H]
+  // aux patch image [P][AR0] (gather mode: staged by LDS-DMA in front of the window pieces).  Training: it lies over the head's
+  // vectors h / dlogits / dh / dz (+ AUXX floats in front of them): the image is consumed before barrier W, those vectors live
+  // from barrier 1 to the patch's last barrier.  Eval: conv waves run a patch ahead of the head, so it has its own floats.
+  static constexpr int AUXF = ((P * AR0 + 63) / 64) * 64;
+  static constexpr int NAUXP = AUXF / 64;             // 256-byte LDS-DMA pieces of the aux image
+  static constexpr int HEADV = H + KMAX + H + ZS;     // floats of h, dlogits, dh, dz
+  static constexpr int AUXX = TR ? (AUXF > HEADV ? AUXF - HEADV : 0) : AUXF;
+  static constexpr int oAux = oZP + NB * ZPW;
+  static constexpr int oHv = oAux + AUXX;             // h [H]
   static constexpr int oDl = oHv + H;                 // dlogits [KMAX]
   static constexpr int oDh = oDl + KMAX;              // dh [H]
   static constexpr int oDz = oDh + H;                 // dL/dz [ZS]
+  static_assert(!TR || oDz + ZS - oAux >= AUXF, "aux image over the head vectors");
   static constexpr int oSlab = oDz + (TR ? ZS : 0);   // [NQ][SLAB] UNIT weight gradients of the current patch, one copy per quad partial
   static constexpr int NCOPY = TR ? NQ : 0;
-  static constexpr int oW2 = oSlab + NCOPY * Sh::SLAB;   // fc2.weight [K rounded up to 4][W2S]  (run-time K)
+  static constexpr int oDzix = oSlab + NCOPY * Sh::SLAB;  // training: per 16-byte slab piece, the dz indices of its 4 elements (8 bits each)
+  static constexpr int NDZ = TR ? ((Sh::SLAB / 4 + 3) / 4) * 4 : 0;
+  static constexpr int oW2 = oDzix + NDZ;                // fc2.weight [K rounded up to 4][W2S]  (run-time K)
   static constexpr int FIXED = oW2;
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
   // (a lane's 16-byte gather piece must not straddle a pixel — or, without pixel padding, a window row)
@@ -422,15 +433,38 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     }
   };
 
+  // The aux patch image [P][AR0] by LDS-DMA, 64 floats per piece, piece q by wave q % NW — IN FRONT of that wave's window
+  // pieces: requests of one CU are served in issue order, an aux row queued behind 100 KB of window would arrive with it.
+  auto issue_aux = [&](int x, int y) {
+    const float* base = a.in.sceneB + ((size_t)x * a.in.WpB + y) * C2;
+    int l_ = lane;
+    OPAQUE(l_);
+#pragma unroll
+    for (int q = 0; q < V::NAUXP; ++q) {
+      if (q % V::NW != wave) continue;
+      const int t = q * 64 + l_;
+      const int pr = t / V::AR0, within = t - pr * V::AR0;
+      dma_piece<4>(base, 0, t < P * V::AR0 ? (pr * a.in.WpB * C2 + within) * 4 : -1, smem + V::oAux + q * 64);
+    }
+  };
+  // Wait until only this wave's window pieces are in flight, i.e. until everything it issued BEFORE them has landed: its
+  // table-staging pieces (first patch) and its aux piece.  (vmcnt counts in issue order; the operand is an immediate, and a
+  // wave issues NK pieces or — its last piece index beyond the image — NK - 1.)
+  auto wait_older_than_gather = [&]() {
+    if (wave + (V::NK - 1) * V::NW < V::NPIECE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK - 1) : "memory");
+  };
+
   // Behind barrier 2, all waves: dL/dz[i] = sum_j fc1.weight[j][i] dh[j] (4 lanes per i), then the workgroup's slab row =
   // sum of the quad copies of the UNIT gradients x dL/dz of each element's channel, in one coalesced pass (streaming stores:
   // next read by the reduce kernel).  A workgroup that walks several patches accumulates in its (L2-resident) global row.
   constexpr int NI = (Sh::SLAB / 4 + V::NT - 1) / V::NT;   // 16-byte slab pieces per thread
-  int dzix[NI];                                            // channel (dz index) of each of this thread's slab elements, 8 bits each
-  if constexpr (TR) {
+  // channel (dz index) of each slab element, 8 bits each, one word per 16-byte piece: a table in LDS, written once here —
+  // kept in registers across the patch loop it is spilled to scratch (and scratch lines are written back at kernel end)
+  if constexpr (TR && !UNIT) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      dzix[i] = 0;
+      int dzix = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int p = 4 * (tid + i * V::NT) + e;
@@ -443,15 +477,18 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         else if (p < Sh::oB2w) ix = F + p - Sh::oB1b;
         else if (p < Sh::oB2b) ix = F + (p - Sh::oB2w) / 9;
         else if (p < Sh::NCONV) ix = F + p - Sh::oB2b;
-        dzix[i] |= ix << (8 * e);
+        dzix |= ix << (8 * e);
       }
+      if (tid + i * V::NT < Sh::SLAB / 4) reinterpret_cast<int*>(smem + V::oDzix)[tid + i * V::NT] = dzix;
     }
   }
   auto scale_and_store = [&](int it, int b) {
+    int tid_ = tid;
+    OPAQUE(tid_);            // (addresses formed here, not carried — spilled — across the patch loop)
     if constexpr (UNIT) {   // the patch's unit gradients (sum of the quad copies), unscaled, to its own row
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int t = tid + i * V::NT;
+        const int t = tid_ + i * V::NT;
         if (t < Sh::SLAB / 4) {
           float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * t);
 #pragma unroll
@@ -466,7 +503,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       return;
     }
     float* sDz = smem + V::oDz;
-    for (int t = tid; t < 4 * F2; t += V::NT) {          // (whole quads: NT and 4 F2 are multiples of 4)
+    for (int t = tid_; t < 4 * F2; t += V::NT) {         // (whole quads: NT and 4 F2 are multiples of 4)
       const int i = t >> 2, m = t & 3;
       float d = 0.f;
 #pragma unroll
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     LDS_BARRIER();                                       // barrier 3: dz complete
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int t = tid + i * V::NT;
+      const int t = tid_ + i * V::NT;
       if (t < Sh::SLAB / 4) {
         float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * t);
 #pragma unroll
@@ -489,7 +526,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           const float4 u = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * t);
           v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        const int dx = dzix[i];
+        const int dx = reinterpret_cast<const int*>(smem + V::oDzix)[t];
         v.x *= sDz[dx & 255]; v.y *= sDz[(dx >> 8) & 255]; v.z *= sDz[(dx >> 16) & 255]; v.w *= sDz[(dx >> 24) & 255];
         float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB + 4 * t;
         if (it > 0) {
@@ -542,23 +579,24 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       const unsigned aPool = lds_addr(sPool) + 4u * (unsigned)(rc * V::RSP);
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
-        if (it == 0) DMF_STAGE_WAIT();                       // this wave's staging pieces (issued at kernel entry) have landed
-        const float* __restrict__ srcB = a.in.sceneB + ((size_t)(x + rc) * a.in.WpB + y) * C2;
-#pragma unroll
-        for (int i = 0; i < V::AR0; ++i) ax[i] = srcB[i];
-        // barrier X (first patch): the offset table and the staged tables are complete, and every wave's aux-row loads are
-        // in the memory pipeline AHEAD of every wave's window pieces (requests of one CU are served in issue order: an aux
-        // row queued behind 100 KiB of gather arrives with the window)
-        VSTAMP(11);
-        if (it == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the scheduler must not sink the gather below the aux phase (nor hoist that phase above it)
+        // the coordinates are all the gather needs: aux piece, then the window pieces, go out BEFORE the wait for the staged
+        // tables (the scheduler must not sink them below the aux phase, nor hoist that phase above them)
         __builtin_amdgcn_sched_barrier(0);
+        issue_aux(x, y);
         issue_gather(x, y);
         __builtin_amdgcn_sched_barrier(0);
-
-        {   // the next patch's coordinates, a whole patch ahead of their use (behind barrier 0: its lgkmcnt wait would cover them)
+        VSTAMP(11);
+        // barrier X: every wave's staging pieces and aux piece have landed (the aux image is read by all conv waves)
+        wait_older_than_gather();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {   // the next patch's coordinates, a whole patch ahead of their use (behind barrier X: its lgkmcnt wait would cover them)
           const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
           xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
+        }
+        {   // this lane's aux row, by reads the compiler cannot order behind the window pieces (hidden_read)
+          const unsigned aAux = lds_addr(smem + V::oAux) + 4u * (unsigned)(rc * V::AR0);
+#pragma unroll
+          for (int i = 0; i < V::AR0; ++i) ax[i] = hidden_read(aAux, i * 4);
         }
       } else {
         // materialised band-major patches (the reference dataloader's tensors; test / drop-in path)
@@ -591,6 +629,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
 #pragma unroll
         for (int c = 0; c < P; ++c) pw[c] = hidden_read(aPool, c * 4);
         hidden_wait();
+        if constexpr (INMODE == 1) {
+#pragma unroll
+          for (int i = 0; i < V::AR0; ++i) HIDDEN_USE(ax[i]);
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) HIDDEN_USE(w2b[k]);
         HIDDEN_USE(b2b); HIDDEN_USE(bl);
@@ -806,12 +848,18 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     int it = 0;
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
       VSTAMP(11);
-      if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier X
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
+        __builtin_amdgcn_sched_barrier(0);
+        issue_aux(x, y);
         issue_gather(x, y);                              // this wave's share of the window
+        __builtin_amdgcn_sched_barrier(0);
+        wait_older_than_gather();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier X
         const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
         xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
+      } else {
+        if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier X
       }
       int label = 0;
       float dlx = 0.f;
