@@ -142,6 +142,11 @@ struct V2 {
   static constexpr int XF = ((P * RS + 255) / 256) * 256;    // floats, whole pieces
   static constexpr int NPIECE = XF / 256;
   static constexpr int NK = (NPIECE + NW - 1) / NW;   // pieces per wave (all NW waves gather)
+  // A wave issues only its first K0 pieces in front of barrier X and the rest from inside the aux phase (one after each
+  // output column of spat_b): issuing is back-pressured by the memory pipeline, and a wave that issues its whole share first
+  // reaches the barrier — behind which the aux arithmetic of ALL waves waits — thousands of cycles late.
+  static constexpr int K0 = NK > 3 ? 2 : NK;
+  static constexpr int NREST = NK - K0;
   static constexpr int AR0 = P * C2;                  // aux floats per patch row
   static constexpr int RSP = ((P + 3) / 4) * 4;       // row stride of the staged pooling profile
   static constexpr int W2S = ((H / 4) | 1) * 4;       // row stride of the staged fc2.weight
@@ -154,19 +159,20 @@ struct V2 {
   static constexpr int NZB = TR ? 1 : 2;
   static constexpr int oZP = oZ + NZB * ZS;           // per conv wave: the quad partials of its channels' pooled features [NB][ZPW]
   static constexpr int ZPW = ((2 * CPW * NQ + 15) / 16) * 16;
-  // aux patch image [P][AR0] (gather mode: staged by LDS-DMA in front of the window pieces).  Training: it lies over the head's
-  // vectors h / dlogits / dh / dz (+ AUXX floats in front of them): the image is consumed before barrier W, those vectors live
-  // from barrier 1 to the patch's last barrier.  Eval: conv waves run a patch ahead of the head, so it has its own floats.
-  static constexpr int AUXF = ((P * AR0 + 63) / 64) * 64;
+  // aux patch image [P][AR0] of a workgroup's FIRST patch (gather mode: staged by LDS-DMA in front of the window pieces).  It
+  // lies over the head's vectors h / dlogits / dh (/ dz) (+ AUXX floats in front of them): the image is consumed before the
+  // first barrier W, those vectors are first written behind the first barrier 1.
+  static constexpr int AR0P = (AR0 + 3) & ~3;         // image row stride: 16-byte aligned rows (read by ds_read_b128)
+  static constexpr int AUXF = ((P * AR0P + 63) / 64) * 64;
   static constexpr int NAUXP = AUXF / 64;             // 256-byte LDS-DMA pieces of the aux image
-  static constexpr int HEADV = H + KMAX + H + ZS;     // floats of h, dlogits, dh, dz
-  static constexpr int AUXX = TR ? (AUXF > HEADV ? AUXF - HEADV : 0) : AUXF;
+  static constexpr int HEADV = H + KMAX + H + (TR ? ZS : 0);     // floats of h, dlogits, dh, dz
+  static constexpr int AUXX = AUXF > HEADV ? AUXF - HEADV : 0;
   static constexpr int oAux = oZP + NB * ZPW;
   static constexpr int oHv = oAux + AUXX;             // h [H]
   static constexpr int oDl = oHv + H;                 // dlogits [KMAX]
   static constexpr int oDh = oDl + KMAX;              // dh [H]
   static constexpr int oDz = oDh + H;                 // dL/dz [ZS]
-  static_assert(!TR || oDz + ZS - oAux >= AUXF, "aux image over the head vectors");
+  static_assert(oDz + (TR ? ZS : 0) - oAux >= AUXF, "aux image over the head vectors");
   static constexpr int oSlab = oDz + (TR ? ZS : 0);   // [NQ][SLAB] UNIT weight gradients of the current patch, one copy per quad partial
   static constexpr int NCOPY = TR ? NQ : 0;
   static constexpr int oDzix = oSlab + NCOPY * Sh::SLAB;  // training: per 16-byte slab piece, the dz indices of its 4 elements (8 bits each)
@@ -176,7 +182,7 @@ struct V2 {
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
   // (a lane's 16-byte gather piece must not straddle a pixel — or, without pixel padding, a window row)
   static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && P <= 16 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
-                             P * RSP <= 2 * NT && NK <= 16 && (CS == CW ? (P * CW) % 4 == 0 : CW % 4 == 0);
+                             P * RSP <= 2 * NT && NK <= 16 && NREST <= P && (CS == CW ? (P * CW) % 4 == 0 : CW % 4 == 0);
 };
 
 // LDS reads the compiler's waitcnt pass cannot see.  It orders EVERY LDS access it knows of behind all outstanding
@@ -188,6 +194,12 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 __device__ __forceinline__ float hidden_read(unsigned addr, int off) {
   float v;
   asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off) : "memory");
+  return v;
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v hidden_read4(unsigned addr, int off) {      // (16-byte aligned address)
+  f4v v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(off) : "memory");
   return v;
 }
 __device__ __forceinline__ void hidden_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -254,9 +266,12 @@ __device__ __forceinline__ float quad_sum(float v) {     // over the 4 lanes of 
 template <int P>
 struct ConvRows { float y1u[P], y1d[P], gq[P]; };
 
-template <int P, bool RD>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// hook(c) runs after output column c: the aux branch issues the rest of the window gather from there (see the kernel)
+template <int P, bool RD, class Hook = NoHook>
 __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
-                                             ConvRows<P>& t, float& z) {
+                                             ConvRows<P>& t, float& z, Hook&& hook = Hook()) {
 #pragma unroll
   for (int c = 0; c < P; ++c) { t.y1u[c] = lane_above<RD>(y1c[c]); t.y1d[c] = lane_below<RD>(y1c[c]); }
   z = 0.f;
@@ -274,6 +289,7 @@ __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float 
     }
     t.gq[c] = y > 0.f ? pw[c] : 0.f;
     z = fmaf(t.gq[c], y, z);
+    hook(c);
   }
 }
 
@@ -316,11 +332,11 @@ __device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float 
   }
 }
 
-template <int P, bool TR, bool RD>
+template <int P, bool TR, bool RD, class Hook = NoHook>
 __device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
-                                         float& z, float (&dw)[9], float& db, float (&dy)[P]) {
+                                         float& z, float (&dw)[9], float& db, float (&dy)[P], Hook&& hook = Hook()) {
   ConvRows<P> t;
-  conv_row_fwd<P, RD>(y1c, w, bias, pw, t, z);
+  conv_row_fwd<P, RD>(y1c, w, bias, pw, t, z, hook);
   if constexpr (TR) conv_row_bwd<P, RD>(y1c, w, t, dw, db, dy);
 }
 
@@ -406,7 +422,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   static_assert(Sh::NCONV % 4 == 0, "conv parameters in whole 16-byte pieces");
   // This wave's share of the gather: pieces p = wave + k NW of the window image.  Lane l of piece p holds image floats
   // n = 256 p + 4 l .. + 3 = pixel n / CS, bands n % CS ..; its scene offset is ((row Wp + col) C + band) floats.
-  auto issue_gather = [&](int x, int y) {
+  // pieces [k0, k1) of this wave's share
+  auto issue_gather = [&](int x, int y, int k0, int k1) {
     const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * V::CW;     // (32-bit words: HF scenes hold two bands in each)
     const int rowskip = (a.in.Wp - P) * V::CW;               // words between the end of a window row and the start of the next
     int l_ = lane;
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
                                                              // waits for every piece issued before it
 #pragma unroll
     for (int k = 0; k < V::NK; ++k) {
+      if (k < k0 || k >= k1) continue;
       const int p = wave + k * V::NW;
       const int n = 256 * p + 4 * l_;
       int off;
@@ -443,16 +461,20 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     for (int q = 0; q < V::NAUXP; ++q) {
       if (q % V::NW != wave) continue;
       const int t = q * 64 + l_;
-      const int pr = t / V::AR0, within = t - pr * V::AR0;
-      dma_piece<4>(base, 0, t < P * V::AR0 ? (pr * a.in.WpB * C2 + within) * 4 : -1, smem + V::oAux + q * 64);
+      const int pr = t / V::AR0P, within = t - pr * V::AR0P;
+      dma_piece<4>(base, 0, (pr < P && within < V::AR0) ? (pr * a.in.WpB * C2 + within) * 4 : -1, smem + V::oAux + q * 64);
     }
   };
   // Wait until only this wave's window pieces are in flight, i.e. until everything it issued BEFORE them has landed: its
   // table-staging pieces (first patch) and its aux piece.  (vmcnt counts in issue order; the operand is an immediate, and a
   // wave issues NK pieces or — its last piece index beyond the image — NK - 1.)
   auto wait_older_than_gather = [&]() {
-    if (wave + (V::NK - 1) * V::NW < V::NPIECE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK - 1) : "memory");
+    if constexpr (V::K0 < V::NK) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::K0) : "memory");       // (pieces k < K0 <= NK - 1 exist for every wave)
+    } else {
+      if (wave + (V::NK - 1) * V::NW < V::NPIECE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK - 1) : "memory");
+    }
   };
 
   // Behind barrier 2, all waves: dL/dz[i] = sum_j fc1.weight[j][i] dh[j] (4 lanes per i), then the workgroup's slab row =
@@ -572,31 +594,54 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
       // ------------------------------------------------------------------ aux row -> registers, window -> LDS
       float ax[V::AR0];
+      // gather mode: the aux row arrives as whole 16-byte vectors + a scalar tail, each ONE asm output (LDS reads on the first
+      // patch, global loads later), unpacked into ax[] only behind the wait: element moves of a vector result are ordinary
+      // instructions the compiler may place in front of a wait it cannot see
+      constexpr int NV4 = V::AR0 / 4, NR1 = V::AR0 % 4;
+      f4v axv[NV4 > 0 ? NV4 : 1];
+      float axt[NR1 > 0 ? NR1 : 1];
       float zb;
       {
       DMF_ROLES();
       const unsigned aTh = lds_addr(sTh) + 4u * (unsigned)f;           // hidden-read bases (bytes)
       const unsigned aPool = lds_addr(sPool) + 4u * (unsigned)(rc * V::RSP);
+      int gx = 0, gy = 0;                                  // this patch's coordinates, for the pieces issued from the aux phase
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
-        // the coordinates are all the gather needs: aux piece, then the window pieces, go out BEFORE the wait for the staged
-        // tables (the scheduler must not sink them below the aux phase, nor hoist that phase above them)
+        gx = x; gy = y;
+        // (the scheduler must not sink the gather below the aux phase, nor hoist that phase above it)
         __builtin_amdgcn_sched_barrier(0);
-        issue_aux(x, y);
-        issue_gather(x, y);
-        __builtin_amdgcn_sched_barrier(0);
-        VSTAMP(11);
-        // barrier X: every wave's staging pieces and aux piece have landed (the aux image is read by all conv waves)
-        wait_older_than_gather();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {   // the next patch's coordinates, a whole patch ahead of their use (behind barrier X: its lgkmcnt wait would cover them)
+        if (it == 0) {
+          // first patch: the coordinates are all the gather needs — aux piece, then the first window pieces, go out BEFORE
+          // the wait for the staged tables; barrier X: every wave's staging pieces and aux piece have landed
+          issue_aux(x, y);
+          issue_gather(x, y, 0, V::K0);
+          __builtin_amdgcn_sched_barrier(0);
+          VSTAMP(11);
+          wait_older_than_gather();
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // this lane's aux row, by reads the compiler cannot order behind the window pieces (hidden_read)
+          const unsigned aAux = lds_addr(smem + V::oAux) + 4u * (unsigned)(rc * V::AR0P);
+#pragma unroll
+          for (int j = 0; j < NV4; ++j) axv[j] = hidden_read4(aAux, j * 16);
+#pragma unroll
+          for (int i = 0; i < NR1; ++i) axt[i] = hidden_read(aAux, (4 * NV4 + i) * 4);
+        } else {
+          // later patches: nothing to wait for and no barrier (the conv waves start without waiting for the head wave's
+          // tail) — the lane's aux row straight into registers, ahead of the window pieces in the memory pipeline.  Inline
+          // asm like the reads above: loads the compiler knows of would make it wait for them (and for every piece behind
+          // them) before the other path's asm may write the same registers.
+          const float* srcB = a.in.sceneB + ((size_t)(x + rc) * a.in.WpB + y) * C2;
+#pragma unroll
+          for (int j = 0; j < NV4; ++j) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(axv[j]) : "v"(srcB), "n"(16 * j) : "memory");
+#pragma unroll
+          for (int i = 0; i < NR1; ++i) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(axt[i]) : "v"(srcB), "n"(4 * (4 * NV4 + i)) : "memory");
+          issue_gather(x, y, 0, V::K0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // the next patch's coordinates, a whole patch ahead of their use
           const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
           xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
-        }
-        {   // this lane's aux row, by reads the compiler cannot order behind the window pieces (hidden_read)
-          const unsigned aAux = lds_addr(smem + V::oAux) + 4u * (unsigned)(rc * V::AR0);
-#pragma unroll
-          for (int i = 0; i < V::AR0; ++i) ax[i] = hidden_read(aAux, i * 4);
         }
       } else {
         // materialised band-major patches (the reference dataloader's tensors; test / drop-in path)
@@ -630,8 +675,14 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         for (int c = 0; c < P; ++c) pw[c] = hidden_read(aPool, c * 4);
         hidden_wait();
         if constexpr (INMODE == 1) {
+          wait_older_than_gather();      // later patches: the aux row's loads (first patch: already waited for in front of barrier X)
 #pragma unroll
-          for (int i = 0; i < V::AR0; ++i) HIDDEN_USE(ax[i]);
+          for (int j = 0; j < NV4; ++j) {
+            HIDDEN_USE(axv[j]);
+            ax[4 * j] = axv[j].x; ax[4 * j + 1] = axv[j].y; ax[4 * j + 2] = axv[j].z; ax[4 * j + 3] = axv[j].w;
+          }
+#pragma unroll
+          for (int i = 0; i < NR1; ++i) { HIDDEN_USE(axt[i]); ax[4 * NV4 + i] = axt[i]; }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) HIDDEN_USE(w2b[k]);
@@ -649,7 +700,17 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           for (int k = 0; k < C2; ++k) v = fmaf(wl[k], ax[c * C2 + k], v);
           y1b[c] = relu_lim(v, lim);
         }
-        conv_row<P, TR, V::ROWDPP>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb);
+        // (the rest of this wave's window pieces leaves from here, one per output column)
+        auto rest = [&](int c) {
+          if constexpr (INMODE == 1 && V::NREST > 0) {
+            if (c < V::NREST) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_gather(gx, gy, V::K0 + c, V::K0 + c + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        };
+        conv_row<P, TR, V::ROWDPP>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb, rest);
         zb = quad_sum(zb);
         if constexpr (TR) {
 #pragma unroll
@@ -851,11 +912,15 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
         __builtin_amdgcn_sched_barrier(0);
-        issue_aux(x, y);
-        issue_gather(x, y);                              // this wave's share of the window
+        if (it == 0) issue_aux(x, y);
+        issue_gather(x, y, 0, V::K0);                    // this wave's share of the window: the first pieces ...
         __builtin_amdgcn_sched_barrier(0);
-        wait_older_than_gather();
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier X
+        if (it == 0) {
+          wait_older_than_gather();
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // barrier X (first patch)
+        }
+        issue_gather(x, y, V::K0, V::NK);                // ... and the rest (nothing else to do until barrier 1)
+        __builtin_amdgcn_sched_barrier(0);
         const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
         xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
       } else {

@@ -48,7 +48,7 @@ def main():
             pmc.setdefault(k, {})[ctr] = {'n': len(v), 'median_KiB': statistics.median(v), 'mean_KiB': statistics.mean(v)}
     summary = {'round': tag, 'kernels': pmc}
     for k, v in pmc.items():
-        train = ('patch_kernel' in k and ', 1>' in k) or ('patch_v2_kernel' in k and ', 1, 1>' in k)     # MODE_TRAIN (gather input)
+        train = ('patch_kernel' in k and ', 1>' in k) or ('patch_v2_kernel' in k and ', 1, 1, false>' in k)     # MODE_TRAIN (gather input)
         if train and 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
             fetch = 2 * v['FETCH_SIZE']['median_KiB'] * 1024
             write = v['WRITE_SIZE']['median_KiB'] * 1024
@@ -95,5 +95,33 @@ def main():
         print(json.dumps(res, indent=1)[:1500])
 
 
+
+
+def configs_md(tag):
+    """gpurun_out/<tag>_config_lines.jsonl (tools/collect_r2.sh: a '# command' line, then bench.py's JSON line) -> profiles/<tag>_configs.md"""
+    src = os.path.join(ROOT, 'gpurun_out', tag + '_config_lines.jsonl')
+    if not os.path.exists(src):
+        return
+    rows, cmd = [], None
+    for line in open(src):
+        line = line.strip()
+        if line.startswith('#'):
+            cmd = line[2:]
+        elif line.startswith('{'):
+            d = json.loads(line)
+            r = d['roofline']
+            extra = ''
+            if 'loss_scaler' in d:
+                extra = '; loss scale %g, %d skipped steps' % (d['loss_scaler']['scale'], d['loss_scaler']['skipped_steps'])
+            rows.append('| `%s` | %s | %.3g %s, %.1f us/step; dominant kernel %.2f us, %s fraction %.3f (%s)%s |' % (
+                cmd, d['config']['workload'].split(';')[0], d['value'], d['unit'], d['ms_per_step'] * 1e3, r['kernel_ms'] * 1e3,
+                'HBM-roof' if r['bound'] == 'hbm' else 'MFMA-peak', r['frac'], d['dtype'].split(',')[0], extra))
+    with open(os.path.join(ROOT, 'profiles', tag + '_configs.md'), 'w') as f:
+        f.write('# Round-%s bench lines of the BASELINE.json configurations and the batch sweep (1 x MI355X; from the repo root)\n\n' % tag[1:])
+        f.write('`value` counts training patches (config 4: stacked stream patches); kernel time = HIP events in `bench.py`.\n\n')
+        f.write('| command | workload | result |\n|---|---|---|\n' + '\n'.join(rows) + '\n')
+
+
 if __name__ == '__main__':
     main()
+    configs_md(sys.argv[1] if len(sys.argv) > 1 else 'r1')
