@@ -192,6 +192,16 @@ class Solver(BaseSolver):
     def _valid_pass(self, best_loss):
         ce = torch.nn.CrossEntropyLoss()
         val_loss = 0.0
+        if self.fast:
+            # The reference adds `loss.item() * n` per batch and stops once the sum passes best_loss (mainsolver.py:65-75):
+            # one host sync per batch.  Here the same double-precision sum stays on the device and is read once; the terms
+            # are non-negative, so "the full sum is below best_loss" decides exactly what the early exit decides.
+            tot = torch.zeros((), dtype=torch.float64, device=self.DEVICE)
+            with torch.no_grad():
+                for batch in self.valid_index_loader:
+                    logits, target, _, _ = self._forward_batch(batch)
+                    tot += ce(logits, target).double() * target.shape[0]
+            return float(tot.item())
         with torch.no_grad():
             for batch in (self.valid_index_loader if self.fast else self.valid_loader):
                 logits, target, _, _ = self._forward_batch(batch)
