@@ -119,7 +119,12 @@ def exchange_matches_rccl(eng, comm, pg, step, backend):
         g_r = g_r.to(g_x.device)
     torch.cuda.synchronize()
     tol = 1e-5 * float(g_r.abs().max()) + 1e-12                 # the two sums differ in order only
-    return comm.status() == 0 and bool((g_x - g_r).abs().max() <= tol)
+    err, st = float((g_x - g_r).abs().max()), comm.status()
+    if st != 0 or not err <= tol:
+        print('[bench] rank %d, warm-up step %d: exchange status %d, max |exchange - all_reduce| = %.3e (tolerance %.3e, max |sum| %.3e)'
+              % (dist.get_rank(pg), step, st, err, tol, float(g_r.abs().max())), file=sys.stderr, flush=True)
+        return False
+    return True
 
 
 def main():
