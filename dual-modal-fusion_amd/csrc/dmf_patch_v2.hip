@@ -145,7 +145,8 @@ struct V2 {
   // A wave issues only its first K0 pieces in front of barrier X and the rest from inside the aux phase (one after each
   // output column of spat_b): issuing is back-pressured by the memory pipeline, and a wave that issues its whole share first
   // reaches the barrier — behind which the aux arithmetic of ALL waves waits — thousands of cycles late.
-  static constexpr int K0 = NK > 3 ? 2 : NK;
+  static constexpr bool SX = Sh::S > 1;               // aux modality at S x the resolution (lift_b = S x S stride-S conv)
+  static constexpr int K0 = (NK > 3 && !SX) ? 2 : NK;
   static constexpr int NREST = NK - K0;
   static constexpr int AR0 = P * C2;                  // aux floats per patch row
   static constexpr int RSP = ((P + 3) / 4) * 4;       // row stride of the staged pooling profile
@@ -177,11 +178,20 @@ struct V2 {
   static constexpr int NCOPY = TR ? NQ : 0;
   static constexpr int oDzix = oSlab + NCOPY * Sh::SLAB;  // training: per 16-byte slab piece, the dz indices of its 4 elements (8 bits each)
   static constexpr int NDZ = TR ? ((Sh::SLAB / 4 + 3) / 4) * 4 : 0;
-  static constexpr int oW2 = oDzix + NDZ;                // fc2.weight [K rounded up to 4][W2S]  (run-time K)
+  // S > 1: the aux patch image [S P rows][RL = S P C2 floats] of EVERY patch lives in LDS (a lane needs S rows of it: too
+  // many for registers).  The 16-byte chunks of a row are rotated by the PATCH row r = row / S, so that the 16 row-lanes
+  // of a ds_read_b128 service group, whose rows are S RL floats = a multiple of 256 bytes apart, land on different banks;
+  // the LDS-DMA fill applies the rotation through its per-lane source addresses.
+  static constexpr int RL = Sh::SP * C2;
+  static constexpr int NC4 = RL / 4;
+  static constexpr int AUXS = SX ? ((Sh::SP * RL + 255) / 256) * 256 : 0;
+  static constexpr int NAUXS = AUXS / 256;            // 1-KiB LDS-DMA pieces
+  static constexpr int oAuxS = oDzix + NDZ;
+  static constexpr int oW2 = oAuxS + AUXS;               // fc2.weight [K rounded up to 4][W2S]  (run-time K)
   static constexpr int FIXED = oW2;
   static int lds_bytes(int K) { return (FIXED + ((K + 3) & ~3) * W2S) * 4; }
   // (a lane's 16-byte gather piece must not straddle a pixel — or, without pixel padding, a window row)
-  static constexpr bool OK = Sh::S == 1 && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && P <= 16 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
+  static constexpr bool OK = (Sh::S == 1 || (Sh::S == 4 && RL % 4 == 0 && NC4 >= P)) && C2 <= 4 && Cg % 4 == 0 && LPC <= 32 && P <= 16 && CPW >= 2 && NW <= 12 && H == 64 && F2 <= 128 &&
                              P * RSP <= 2 * NT && NK <= 16 && NREST <= P && (CS == CW ? (P * CW) % 4 == 0 : CW % 4 == 0);
 };
 
@@ -465,6 +475,24 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       dma_piece<4>(base, 0, (pr < P && within < V::AR0) ? (pr * a.in.WpB * C2 + within) * 4 : -1, smem + V::oAux + q * 64);
     }
   };
+  // S > 1: the whole aux patch image, 1-KiB pieces; lane l of piece q holds image floats n = 256 q + 4 l .. + 3 = row n / RL,
+  // PHYSICAL chunk (n % RL) / 4 = logical chunk rotated by the patch row (see V2::RL)
+  auto issue_aux_s = [&](int x, int y) {
+    if constexpr (V::SX) {
+      const float* base = a.in.sceneB + ((size_t)(Sh::S * x) * a.in.WpB + Sh::S * y) * C2;
+      int l_ = lane;
+      OPAQUE(l_);
+#pragma unroll
+      for (int q = 0; q < V::NAUXS; ++q) {
+        if (q % V::NW != wave) continue;
+        const int n = 256 * q + 4 * l_;
+        const int row = n / V::RL, pc = (n - row * V::RL) >> 2;
+        int lc = pc - row / Sh::S;
+        lc += lc < 0 ? V::NC4 : 0;
+        dma_piece<16>(base, 0, row < Sh::SP ? (row * a.in.WpB * C2 + 4 * lc) * 4 : -1, smem + V::oAuxS + q * 256);
+      }
+    }
+  };
   // Wait until only this wave's window pieces are in flight, i.e. until everything it issued BEFORE them has landed: its
   // table-staging pieces (first patch) and its aux piece.  (vmcnt counts in issue order; the operand is an immediate, and a
   // wave issues NK pieces or — its last piece index beyond the image — NK - 1.)
@@ -611,7 +639,15 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         gx = x; gy = y;
         // (the scheduler must not sink the gather below the aux phase, nor hoist that phase above it)
         __builtin_amdgcn_sched_barrier(0);
-        if (it == 0) {
+        if constexpr (V::SX) {
+          // S > 1: aux image and window of every patch through LDS, complete before the aux phase (the windows of these
+          // shapes are a few KiB: nothing to overlap) — vmcnt(0) also covers the staged tables of the first patch
+          issue_aux_s(x, y);
+          issue_gather(x, y, 0, V::NK);
+          __builtin_amdgcn_sched_barrier(0);
+          VSTAMP(11);
+          __syncthreads();
+        } else if (it == 0) {
           // first patch: the coordinates are all the gather needs — aux piece, then the first window pieces, go out BEFORE
           // the wait for the staged tables; barrier X: every wave's staging pieces and aux piece have landed
           issue_aux(x, y);
@@ -645,11 +681,23 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         }
       } else {
         // materialised band-major patches (the reference dataloader's tensors; test / drop-in path)
-        const float* __restrict__ srcB = a.in.b + (size_t)(boff + b) * C2 * P2;
+        if constexpr (V::SX) {
+          // the aux patch [C2][S P][S P] (band-major) into the rotated LDS image
+          const float* __restrict__ srcB = a.in.b + (size_t)(boff + b) * C2 * Sh::PB;
+          for (int e = tid; e < C2 * Sh::PB; e += V::NB * 64) {
+            const int k = e / Sh::PB, pix = e - k * Sh::PB, row = pix / Sh::SP, col = pix - row * Sh::SP;
+            const int m = col * C2 + k;                    // logical float index inside the image row
+            int pc = (m >> 2) + row / Sh::S;
+            pc -= pc >= V::NC4 ? V::NC4 : 0;
+            smem[V::oAuxS + row * V::RL + 4 * pc + (m & 3)] = srcB[e];
+          }
+        } else {
+          const float* __restrict__ srcB = a.in.b + (size_t)(boff + b) * C2 * P2;
 #pragma unroll
-        for (int c = 0; c < P; ++c)
+          for (int c = 0; c < P; ++c)
 #pragma unroll
-          for (int k = 0; k < C2; ++k) ax[c * C2 + k] = srcB[k * P2 + rc * P + c];
+            for (int k = 0; k < C2; ++k) ax[c * C2 + k] = srcB[k * P2 + rc * P + c];
+        }
         if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // barrier X
         const float* __restrict__ srcA = a.in.a + (size_t)(boff + b) * Sh::C * P2;
         for (int e = tid; e < Sh::C * P2; e += V::NB * 64) {
@@ -657,24 +705,26 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           if constexpr (HF) reinterpret_cast<_Float16*>(smem + V::oX + (pix / P) * V::RS + (pix % P) * V::CS)[cb] = (_Float16)srcA[e];
           else smem[V::oX + (pix / P) * V::RS + (pix % P) * V::CS + cb] = srcA[e];
         }
+        if constexpr (V::SX) __syncthreads();                // the aux image (written above by all conv waves) is read next
       }
       VSTAMP(2);
 
       // ------------------------------------------------------------------ aux branch, under the window gather
-      float dwb[9], dbb = 0.f, dwl[C2], dbl = 0.f;
+      constexpr int TB = Sh::TB;                             // taps of lift_b: C2 S S
+      float dwb[9], dbb = 0.f, dwl[TB], dbl = 0.f;
       {
-        float w2b[9], wl[C2], pw[P], b2b, bl;
+        float w2b[9], wl[TB], pw[P], b2b, bl;
         // (the channel-dependent part of an offset is in the base address, the rest is an instruction immediate)
 #pragma unroll
         for (int k = 0; k < 9; ++k) w2b[k] = hidden_read(aTh + 4u * (unsigned)(f * 8), (Sh::oB2w + k) * 4);          // oB2w + 9f + k
         b2b = hidden_read(aTh, Sh::oB2b * 4);
         bl = hidden_read(aTh, Sh::oB1b * 4);
 #pragma unroll
-        for (int k = 0; k < C2; ++k) wl[k] = hidden_read(aTh + 4u * (unsigned)(f * (C2 - 1)), (Sh::oB1w + k) * 4);   // oB1w + C2 f + k
+        for (int k = 0; k < TB; ++k) wl[k] = hidden_read(aTh + 4u * (unsigned)(f * (TB - 1)), (Sh::oB1w + k) * 4);   // oB1w + TB f + k
 #pragma unroll
         for (int c = 0; c < P; ++c) pw[c] = hidden_read(aPool, c * 4);
         hidden_wait();
-        if constexpr (INMODE == 1) {
+        if constexpr (INMODE == 1 && !V::SX) {
           wait_older_than_gather();      // later patches: the aux row's loads (first patch: already waited for in front of barrier X)
 #pragma unroll
           for (int j = 0; j < NV4; ++j) {
@@ -688,17 +738,46 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         for (int k = 0; k < 9; ++k) HIDDEN_USE(w2b[k]);
         HIDDEN_USE(b2b); HIDDEN_USE(bl);
 #pragma unroll
-        for (int k = 0; k < C2; ++k) HIDDEN_USE(wl[k]);
+        for (int k = 0; k < TB; ++k) HIDDEN_USE(wl[k]);
 #pragma unroll
         for (int c = 0; c < P; ++c) HIDDEN_USE(pw[c]);
 
         float y1b[P], dyb[P];
+        // S > 1: logical float m = 4 j + e of image row S rc + u is pixel column m / C2, band m % C2 = output column
+        // (m / C2) / S, tap ((m % C2) S + u) S + (m / C2) % S; its 16-byte chunk j sits at physical chunk (j + rc) mod NC4
+        const float* auxr = smem + V::oAuxS + (Sh::S * rc) * V::RL;
+        // physical chunk of logical chunk j in this lane's rows (one address per j, the S rows are immediate offsets apart)
+        auto chunk_of = [&](int j) -> int {
+          if constexpr ((V::NC4 & (V::NC4 - 1)) == 0) return (j + rc) & (V::NC4 - 1);
+          else { int pc = j + rc; pc -= pc >= V::NC4 ? V::NC4 : 0; return pc; }
+        };
+        if constexpr (V::SX) {
 #pragma unroll
-        for (int c = 0; c < P; ++c) {
-          float v = bl;
+          for (int c = 0; c < P; ++c) y1b[c] = bl;
 #pragma unroll
-          for (int k = 0; k < C2; ++k) v = fmaf(wl[k], ax[c * C2 + k], v);
-          y1b[c] = relu_lim(v, lim);
+          for (int j = 0; j < V::NC4; ++j) {
+            const float* ap = auxr + 4 * chunk_of(j);
+#pragma unroll
+            for (int u = 0; u < Sh::S; ++u) {
+              const float4 a4 = *reinterpret_cast<const float4*>(ap + u * V::RL);
+              const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int m = 4 * j + e, cp = m / C2, k = m % C2;
+                y1b[cp / Sh::S] = fmaf(wl[(k * Sh::S + u) * Sh::S + cp % Sh::S], av[e], y1b[cp / Sh::S]);
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < P; ++c) y1b[c] = relu_lim(y1b[c], lim);
+        } else {
+#pragma unroll
+          for (int c = 0; c < P; ++c) {
+            float v = bl;
+#pragma unroll
+            for (int k = 0; k < C2; ++k) v = fmaf(wl[k], ax[c * C2 + k], v);
+            y1b[c] = relu_lim(v, lim);
+          }
         }
         // (the rest of this wave's window pieces leaves from here, one per output column)
         auto rest = [&](int c) {
@@ -714,19 +793,36 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         zb = quad_sum(zb);
         if constexpr (TR) {
 #pragma unroll
-          for (int k = 0; k < C2; ++k) dwl[k] = 0.f;
+          for (int k = 0; k < TB; ++k) dwl[k] = 0.f;
 #pragma unroll
-          for (int c = 0; c < P; ++c) {
-            dbl += dyb[c];
+          for (int c = 0; c < P; ++c) dbl += dyb[c];
+          if constexpr (V::SX) {
 #pragma unroll
-            for (int k = 0; k < C2; ++k) dwl[k] = fmaf(dyb[c], ax[c * C2 + k], dwl[k]);
+            for (int j = 0; j < V::NC4; ++j) {
+              const float* ap = auxr + 4 * chunk_of(j);
+#pragma unroll
+              for (int u = 0; u < Sh::S; ++u) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ap + u * V::RL);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int m = 4 * j + e, cp = m / C2, k = m % C2, t = (k * Sh::S + u) * Sh::S + cp % Sh::S;
+                  dwl[t] = fmaf(dyb[cp / Sh::S], av[e], dwl[t]);
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < P; ++c)
+#pragma unroll
+              for (int k = 0; k < C2; ++k) dwl[k] = fmaf(dyb[c], ax[c * C2 + k], dwl[k]);
           }
 #pragma unroll
           for (int k = 0; k < 9; ++k) dwb[k] = quad_sum(dwb[k]);
           dbb = quad_sum(dbb);
           dbl = quad_sum(dbl);
 #pragma unroll
-          for (int k = 0; k < C2; ++k) dwl[k] = quad_sum(dwl[k]);
+          for (int k = 0; k < TB; ++k) dwl[k] = quad_sum(dwl[k]);
         }
       }
       VSTAMP(3);
@@ -739,7 +835,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
           sl[Sh::oB2b + f] = dbb;
           sl[Sh::oB1b + f] = dbl;
 #pragma unroll
-          for (int k = 0; k < C2; ++k) sl[Sh::oB1w + f * C2 + k] = dwl[k];
+          for (int k = 0; k < TB; ++k) sl[Sh::oB1w + f * TB + k] = dwl[k];
         }
       }
       }
@@ -912,10 +1008,13 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
         __builtin_amdgcn_sched_barrier(0);
-        if (it == 0) issue_aux(x, y);
+        if constexpr (V::SX) issue_aux_s(x, y);
+        else if (it == 0) issue_aux(x, y);
         issue_gather(x, y, 0, V::K0);                    // this wave's share of the window: the first pieces ...
         __builtin_amdgcn_sched_barrier(0);
-        if (it == 0) {
+        if constexpr (V::SX) {
+          __syncthreads();                               // (every patch: the aux image is complete, see the conv waves)
+        } else if (it == 0) {
           wait_older_than_gather();
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // barrier X (first patch)
         }
@@ -925,6 +1024,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         xn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn)]; yn = ((cint*)a.in.xy)[2 * (size_t)(boff + bn) + 1];
       } else {
         if (it == 0) { DMF_STAGE_WAIT(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier X
+        if constexpr (V::SX) __syncthreads();            // (the conv waves' aux image, see there)
       }
       int label = 0;
       float dlx = 0.f;
@@ -1178,8 +1278,9 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
 // unit-gradient kernels for both input modes, the unit backward kernel, and its line in the supported-shape listing.
 // A row must satisfy V2<>::OK (S = 1, whole 16-byte band chunks per group, <= 12 waves) and fit 160 KiB of LDS at the
 // run-time K (v2_fits): 13x13 patches of a 200-band scene do not (the window alone is 135 KB) — no instance can exist
-// for them on this design; 224 bands at gmf.width 40 have no group count that divides both (G | gcd(224, 40) = 8 gives
-// 5 channels per group, but a group's bands must be whole 16-byte chunks shared by 4-channel multiples: M % 4 == 0).
+// for them on this design; 224 bands at gmf.width 40 (G | gcd(224, 40) = 8: 5 channels per group) would need 175.6 KB here
+// (window 109.6 + three slab-row copies 25.7 + transposed fc1 20.5 + staged theta 8.6 + ...), and the generic kernel owns a
+// group's channels in 4-channel blocks (M % 4 == 0).
 #define DMF_V2_SHAPES(X)                                                                                      \
   X(200, 1, 11, 1, 40, 10, 64) /* BASELINE configs 1-2 */                                                     \
   X(200, 1, 9, 1, 40, 10, 64)                                                                                 \
@@ -1188,7 +1289,9 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
   X(224, 3, 9, 1, 32, 8, 64)                                                                                  \
   X(8, 1, 5, 1, 40, 2, 64)     /* small test scene, equal resolution */                                       \
   X(4, 1, 16, 1, 40, 1, 64)    /* stage 2 of the two-stage path: one 4-band stream + its band mean */          \
-  X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */
+  X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */                                         \
+  X(4, 1, 16, 4, 40, 1, 64)    /* the reference's own data: 4-band MS + PAN at 4x (config.yml:27,77-110) */         \
+  X(8, 1, 5, 4, 40, 2, 64)     /* small test scene, aux at 4x */
 // ... and the rows that also get the fp16-scene kernels (dmf_input.half): a subset, each instance costs compile time
 #define DMF_V2_HALF_SHAPES(X)                                                                                 \
   X(200, 1, 11, 1, 40, 10, 64)                                                                                \

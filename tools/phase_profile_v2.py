@@ -1,6 +1,6 @@
 """Diagnostic: clock stamps of EVERY wavefront of the v2 patch kernel (stamps build, never the shipped library).
 
-    python tools/phase_profile_v2.py [B]
+    python tools/phase_profile_v2.py [B] [panms]
 
 Prints, per wavefront, the median over workgroups of (stamp - kernel entry of that wave) in shader cycles.
 """
@@ -24,16 +24,19 @@ CONV = ['entry', 'prologue', 'gather issued', 'aux done', 'barrierW', 'barrier1'
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    panms = len(sys.argv) > 2 and sys.argv[2] == 'panms'        # the reference's own data shape: 4-band MS + PAN at 4x, 16x16 patches
     cfg = {'patch_size': 11, 'Categories_Number': 17, 'data_city': 's', 'DATA_DICT': {'s': {'size': [145, 145, 200]}},
            'scale': 1, 'aux_bands': 1, 'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
-    primary, aux, label = synth.make_scene(145, 145, 200, 1, 1, seed=0)
+    if panms:
+        cfg.update({'patch_size': 16, 'Categories_Number': 12, 'DATA_DICT': {'s': {'size': [145, 145, 4]}}, 'scale': 4})
+    primary, aux, label = synth.make_scene(145, 145, 4 if panms else 200, 1, 4 if panms else 1, seed=0)
     MS = data_padding(primary, cfg, 'ms').astype(np.float32)
     PAN = data_padding_aux(aux, cfg).astype(np.float32)
     net = Net(cfg).cuda()
     scene = Scene(MS, PAN, 'cuda:0')
     rng = np.random.default_rng(0)
     xy = torch.from_numpy(np.stack([rng.integers(0, 145, B), rng.integers(0, 145, B)], 1).astype(np.int32)).cuda()
-    lab = torch.from_numpy(rng.integers(1, 17, B).astype(np.int32)).cuda()
+    lab = torch.from_numpy(rng.integers(1, 12 if panms else 17, B).astype(np.int32)).cuda()
     nblk = min(B, 256)
     stamps = torch.zeros(nblk * 16 * 16, dtype=torch.int64, device='cuda')
     fn = lib._lib.dmf_debug_set_v2_stamps
@@ -45,7 +48,7 @@ def main():
     n_steps = 120
     rng2 = np.random.default_rng(1)
     xy_all = np.stack([rng2.integers(0, 145, n_steps * B), rng2.integers(0, 145, n_steps * B)], 1).astype(np.int32)
-    lab_all = rng2.integers(1, 17, n_steps * B).astype(np.int32)
+    lab_all = rng2.integers(1, 12 if panms else 17, n_steps * B).astype(np.int32)
     eng = TrainEngine(net, scene, B, lr=1e-3)
     eng.load_plan(xy_all, lab_all)
     eng.run_plan(n_steps, 40)
