@@ -267,6 +267,12 @@ static bool force_v1() {
   return f;
 }
 
+// the conv launches of the attention network: the v2 kernel where it is built for the shape, else the generic one
+static hipError_t conv_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
+  if (!force_v1() && patch_v2_supported(s, mode)) return patch_v2_dispatch(s, mode, a, st);
+  return patch_dispatch(s, mode, a, st);
+}
+
 extern "C" {
 
 int32_t dmf_version(void) { return DMF_VERSION; }
@@ -373,7 +379,7 @@ int32_t dmf_forward_attn(const dmf_shape* s, const dmf_input* in, const float* t
   KArgs a{};
   a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
   a.tokA = tokA; a.tokB = tokB; a.zout = z;
-  if (check(patch_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
+  if (check(conv_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
   AttnTrainArgs t{};
   t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w; t.logits = logits; t.pred = pred; t.wprep = wprep;
   t.oWq = L.off[12]; t.oWk = L.off[13]; t.oWv = L.off[14]; t.oWo = L.off[15];
@@ -418,7 +424,7 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
   KArgs a{};
   a.in = *in; a.theta = theta; a.pool = pool_w; a.K = s->K;
   a.tokA = tokA; a.tokB = tokB; a.zout = z;
-  if (check(patch_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
+  if (check(conv_dispatch(*s, MODE_TOKENS, a, st), "token kernel launch")) return 1;
   AttnTrainArgs t{};
   t.tokA = tokA; t.tokB = tokB; t.zin = z; t.theta = theta; t.pool = pool_w;
   t.labels = labels; t.cursor = in->cursor; t.dlogits = dlogits; t.loss_scale = loss_scale;
@@ -433,7 +439,7 @@ int32_t dmf_train_attn_fwd_bwd(const dmf_shape* s, const dmf_input* in, const fl
   KArgs d{};
   d.in = *in; d.theta = theta; d.pool = pool_w; d.K = s->K;
   d.slab = ws + w.slab; d.dYa = dYa; d.dYb = dYb; d.adam_step = adam_step_dev;
-  return check(patch_dispatch(*s, MODE_DENSE, d, st), "dense conv backward launch");
+  return check(conv_dispatch(*s, MODE_DENSE, d, st), "dense conv backward launch");
 }
 
 int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,

@@ -281,7 +281,7 @@ struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // hook(c) runs after output column c: the aux branch issues the rest of the window gather from there (see the kernel)
 template <int P, bool RD, class Hook = NoHook>
 __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
-                                             ConvRows<P>& t, float& z, Hook&& hook = Hook()) {
+                                             ConvRows<P>& t, float& z, Hook&& hook = Hook(), float* y2 = nullptr) {
 #pragma unroll
   for (int c = 0; c < P; ++c) { t.y1u[c] = lane_above<RD>(y1c[c]); t.y1d[c] = lane_below<RD>(y1c[c]); }
   z = 0.f;
@@ -299,6 +299,7 @@ __device__ __forceinline__ void conv_row_fwd(const float (&y1c)[P], const float 
     }
     t.gq[c] = y > 0.f ? pw[c] : 0.f;
     z = fmaf(t.gq[c], y, z);
+    if (y2 != nullptr) y2[c] = fmaxf(y, 0.f);           // (token mode: the feature map itself)
     hook(c);
   }
 }
@@ -344,9 +345,9 @@ __device__ __forceinline__ void conv_row_bwd(const float (&y1c)[P], const float 
 
 template <int P, bool TR, bool RD, class Hook = NoHook>
 __device__ __forceinline__ void conv_row(const float (&y1c)[P], const float (&w)[9], float bias, const float (&pw)[P],
-                                         float& z, float (&dw)[9], float& db, float (&dy)[P], Hook&& hook = Hook()) {
+                                         float& z, float (&dw)[9], float& db, float (&dy)[P], Hook&& hook = Hook(), float* y2 = nullptr) {
   ConvRows<P> t;
-  conv_row_fwd<P, RD>(y1c, w, bias, pw, t, z, hook);
+  conv_row_fwd<P, RD>(y1c, w, bias, pw, t, z, hook, y2);
   if constexpr (TR) conv_row_bwd<P, RD>(y1c, w, t, dw, db, dy);
 }
 
@@ -369,8 +370,12 @@ __device__ __forceinline__ void gather_piece(const float* base, int soff, int vo
 // join and waits vmcnt(0) there, i.e. for the whole window, before the aux phase.
 template <class Sh, int MODE, int INMODE, bool HF>
 __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
-  constexpr bool TR = (MODE != MODE_FWD);
+  constexpr bool TOK = (MODE == MODE_TOKENS);          // conv stages only: bf16 token maps + pooled features (attention net)
+  constexpr bool DENSE = (MODE == MODE_DENSE);         // conv backward from DENSE dL/dY2 maps (attention net); no head
+  constexpr bool TR = (MODE != MODE_FWD && !TOK);
   constexpr bool UNIT = (MODE == MODE_UNIT);           // forward + unit gradients per patch; loss and scaling happen elsewhere
+  constexpr int RS4 = (Sh::P + 3) & ~3;                // row stride of the dense gradient maps [B][F][P][RS4]
+  constexpr int TKS = 72;                              // token staging: row stride in halves (keeps the 2-byte scatter off one bank)
   using V = V2<Sh, TR, HF>;
   constexpr int P = Sh::P, P2 = Sh::P2, Cg = Sh::Cg, C2 = Sh::C2, F = Sh::F, F2 = Sh::F2, H = Sh::H, QC = V::QC;
   constexpr int LPC = V::LPC, CPW = V::CPW, NQ = V::NQ;
@@ -394,7 +399,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   if (wave == V::NB) __builtin_amdgcn_s_setprio(3);
   else if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
                                                           // wave of a SIMD wins every arbitration and the younger one trails it
-  if ((MODE == MODE_TRAIN || UNIT) && a.adam_step != nullptr && blockIdx.x == 0 && tid == 0) *a.adam_step += 1;
+  if ((MODE == MODE_TRAIN || UNIT || DENSE) && a.adam_step != nullptr && blockIdx.x == 0 && tid == 0) *a.adam_step += 1;
+  if constexpr (TOK) {   // token staging [2][128][TKS] halves behind the fixed regions: zero once (padding tokens / channels stay 0)
+    for (int i = tid; i < 2 * 128 * TKS / 8; i += V::NT) reinterpret_cast<uint4*>(smem + V::oW2)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const int boff = (a.in.cursor != nullptr) ? ((cint*)a.in.cursor)[0] * B : 0;     // epoch-plan offset of this batch
   // first patch's coordinates: requested before anything else (kernarg -> coordinates -> gather is the kernel's longest
   // dependent chain of memory round trips; the table staging below runs under it)
@@ -535,6 +543,28 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   auto scale_and_store = [&](int it, int b) {
     int tid_ = tid;
     OPAQUE(tid_);            // (addresses formed here, not carried — spilled — across the patch loop)
+    if constexpr (DENSE) {  // real gradients (the upstream maps were dense): sum of the quad copies into the workgroup's row
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int t = tid_ + i * V::NT;
+        if (t < Sh::SLAB / 4) {
+          float4 v = *reinterpret_cast<const float4*>(sSlab + 4 * t);
+#pragma unroll
+          for (int c = 1; c < V::NCOPY; ++c) {
+            const float4 u = *reinterpret_cast<const float4*>(sSlab + c * Sh::SLAB + 4 * t);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          }
+          float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB + 4 * t;
+          if (it > 0) {
+            const float4 o = *reinterpret_cast<const float4*>(slab);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(slab) = v;
+        }
+      }
+      if (gridDim.x < (unsigned)B) LDS_BARRIER();        // more patches follow: the copies are rewritten by the next one
+      return;
+    }
     if constexpr (UNIT) {   // the patch's unit gradients (sum of the quad copies), unscaled, to its own row
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -592,6 +622,19 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     if (gridDim.x < (unsigned)B) LDS_BARRIER();          // more patches follow: the copies are rewritten by the next one
   };
   static_assert(F2 <= 255, "dz index in 8 bits");
+  // MODE_TOKENS, behind barrier 1, all waves: the two staged [128][64] bf16 token maps -> global in 16-byte pieces (tokens
+  // beyond P2 and channels beyond F are the zeros the staging was filled with), then a barrier: the next patch rewrites it
+  auto token_out = [&](int b) {
+    const unsigned short* sTok = reinterpret_cast<const unsigned short*>(smem + V::oW2);
+    for (int i = tid; i < 2 * 128 * 8; i += V::NT) {
+      const int mp = i >> 10, rem = i & 1023, t = rem >> 3, pc8 = rem & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(sTok + mp * 128 * TKS + t * TKS + pc8 * 8);
+      unsigned short* dst = (mp ? a.tokB : a.tokA) + ((size_t)b * 128 + t) * 64 + pc8 * 8;
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+    LDS_BARRIER();
+  };
+  (void)token_out;
 
   if (wave < V::NB) {
     // =============================================================================== conv wavefronts
@@ -621,6 +664,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
     int it = 0;
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
       // ------------------------------------------------------------------ aux row -> registers, window -> LDS
+      float y2b[P];                                        // MODE_TOKENS: this lane's row of the aux feature map
       float ax[V::AR0];
       // gather mode: the aux row arrives as whole 16-byte vectors + a scalar tail, each ONE asm output (LDS reads on the first
       // patch, global loads later), unpacked into ax[] only behind the wait: element moves of a vector result are ordinary
@@ -633,6 +677,12 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       DMF_ROLES();
       const unsigned aTh = lds_addr(sTh) + 4u * (unsigned)f;           // hidden-read bases (bytes)
       const unsigned aPool = lds_addr(sPool) + 4u * (unsigned)(rc * V::RSP);
+      float4 ddbv[RS4 / 4];                                // MODE_DENSE: this lane's row of dL/dY2 of the aux branch (in place
+      if constexpr (DENSE) {                               // of the pooling profile); requested ahead of the gather
+        const float* ddb = a.dYb + ((size_t)b * F + f) * (P * RS4) + rc * RS4;
+#pragma unroll
+        for (int q = 0; q < RS4 / 4; ++q) ddbv[q] = *reinterpret_cast<const float4*>(ddb + 4 * q);
+      }
       int gx = 0, gy = 0;                                  // this patch's coordinates, for the pieces issued from the aux phase
       if constexpr (INMODE == 1) {
         const int x = xn, y = yn;
@@ -724,6 +774,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
 #pragma unroll
         for (int c = 0; c < P; ++c) pw[c] = hidden_read(aPool, c * 4);
         hidden_wait();
+        if constexpr (DENSE) {
+#pragma unroll
+          for (int c = 0; c < P; ++c) { const float4 v = ddbv[c / 4]; pw[c] = (c & 3) == 0 ? v.x : (c & 3) == 1 ? v.y : (c & 3) == 2 ? v.z : v.w; }
+        }
         if constexpr (INMODE == 1 && !V::SX) {
           wait_older_than_gather();      // later patches: the aux row's loads (first patch: already waited for in front of barrier X)
 #pragma unroll
@@ -739,8 +793,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
         HIDDEN_USE(b2b); HIDDEN_USE(bl);
 #pragma unroll
         for (int k = 0; k < TB; ++k) HIDDEN_USE(wl[k]);
+        if constexpr (!DENSE) {
 #pragma unroll
-        for (int c = 0; c < P; ++c) HIDDEN_USE(pw[c]);
+          for (int c = 0; c < P; ++c) HIDDEN_USE(pw[c]);
+        }
 
         float y1b[P], dyb[P];
         // S > 1: logical float m = 4 j + e of image row S rc + u is pixel column m / C2, band m % C2 = output column
@@ -789,7 +845,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
             }
           }
         };
-        conv_row<P, TR, V::ROWDPP>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb, rest);
+        conv_row<P, TR, V::ROWDPP>(y1b, w2b, act ? b2b : -1e30f, pw, zb, dwb, dbb, dyb, rest, TOK ? y2b : nullptr);
         zb = quad_sum(zb);
         if constexpr (TR) {
 #pragma unroll
@@ -850,7 +906,9 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       b2a = sTh[Sh::oA2b + f];
 #pragma unroll
       for (int q = 0; q < V::RSP / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(sPool + rc * V::RSP + 4 * q);
+        // (MODE_DENSE: the lane's row of dL/dY2 of the primary branch instead of the pooling profile; RSP == RS4)
+        const float4 v = DENSE ? *reinterpret_cast<const float4*>(a.dYa + ((size_t)b * F + f) * (P * RS4) + rc * RS4 + 4 * q)
+                               : *reinterpret_cast<const float4*>(sPool + rc * V::RSP + 4 * q);
         if (4 * q < P) pw[4 * q] = v.x;
         if (4 * q + 1 < P) pw[4 * q + 1] = v.y;
         if (4 * q + 2 < P) pw[4 * q + 2] = v.z;
@@ -908,7 +966,19 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       }
       float za, dwa[9], dba = 0.f, dya[P];
       ConvRows<P> ta;
-      conv_row_fwd<P, V::ROWDPP>(y1a, w2a, act ? b2a : -1e30f, pw, ta, za);
+      float y2a[P];
+      conv_row_fwd<P, V::ROWDPP>(y1a, w2a, act ? b2a : -1e30f, pw, ta, za, NoHook(), TOK ? y2a : nullptr);
+      if constexpr (TOK) {   // both feature-map rows -> the bf16 staging [map][token = pixel][channel]
+        if (act) {
+          unsigned short* sTok = reinterpret_cast<unsigned short*>(smem + V::oW2);
+#pragma unroll
+          for (int c = 0; c < P; ++c) {
+            const int t = r * P + c;
+            sTok[t * TKS + f] = __builtin_bit_cast(unsigned short, (__bf16)y2a[c]);
+            sTok[128 * TKS + t * TKS + f] = __builtin_bit_cast(unsigned short, (__bf16)y2b[c]);
+          }
+        }
+      }
       za = quad_sum(za);
       {   // pooled features of the wave's channels: quad partials -> wave-private scratch -> one lane per value sums NQ of them
         float* zp = smem + V::oZP + wave * V::ZPW;
@@ -926,6 +996,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       }
       LDS_BARRIER();                                     // barrier 1: pooled features complete
       VSTAMP(5);
+      if constexpr (TOK) { token_out(b); continue; }
       if constexpr (!TR) continue;
       // spat_a's unit backward runs BEHIND barrier 1: the head starts a conv backward earlier, and its chain of LDS round
       // trips (fc1 -> fc2 -> softmax -> dh) begins while the conv waves execute pure vector work instead of queueing behind
@@ -1035,7 +1106,7 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       if (MODE == MODE_BWD) dlx = lane < K ? a.dlogits[(size_t)b * K + lane] : 0.f;
       __syncthreads();                                   // barrier W: window complete (this wave's pieces included)
       VSTAMP(4);
-      if (it == 0) {   // head tables, behind the gather: nobody needs them before barrier 1, and 20 row-strided loads inside
+      if (it == 0 && !TOK && !DENSE) {   // head tables, behind the gather: nobody needs them before barrier 1, and 20 row-strided loads inside
                        // the gather stream would delay every wave's pieces (one memory pipeline per CU)
 #pragma unroll
         for (int q = 0; q < F2 / 4; ++q) w1r[q] = *reinterpret_cast<const float4*>(th + Sh::oFc1w + lane * F2 + 4 * q);
@@ -1066,6 +1137,18 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
       }
       LDS_BARRIER();                                     // barrier 1: pooled features complete
       VSTAMP(5);
+      if constexpr (TOK) {   // pooled features of the conv stages (before attention), then this wave's share of the token copy
+        const float* zb_ = sZ + (it & 1) * V::ZS;
+        if (lane < F2) a.zout[(size_t)b * F2 + lane] = zb_[lane];
+        if (F2 > 64 && 64 + lane < F2) a.zout[(size_t)b * F2 + 64 + lane] = zb_[64 + lane];
+        token_out(b);
+        continue;
+      }
+      if constexpr (DENSE) {   // no head: the gradient maps came from the attention kernel
+        LDS_BARRIER();                                   // barrier 2
+        scale_and_store(it, b);
+        continue;
+      }
       const float* zbuf = sZ + (TR ? 0 : (it & 1)) * V::ZS;
       // fc1 + ReLU: lane j, its weight row in registers, z broadcast from LDS
       float h;
@@ -1292,6 +1375,11 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
   X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */                                         \
   X(4, 1, 16, 4, 40, 1, 64)    /* the reference's own data: 4-band MS + PAN at 4x (config.yml:27,77-110) */         \
   X(8, 1, 5, 4, 40, 2, 64)     /* small test scene, aux at 4x */
+// ... the rows of the attention network (gmf.attention; attention block: F = 40, E = 96), which also get the two launches of
+// its train step / forward that are conv work: MODE_TOKENS and MODE_DENSE
+#define DMF_V2_ATTN_SHAPES(X)                                                                                 \
+  X(200, 1, 11, 1, 40, 10, 64)                                                                                \
+  X(8, 1, 5, 1, 40, 2, 64)
 // ... and the rows that also get the fp16-scene kernels (dmf_input.half): a subset, each instance costs compile time
 #define DMF_V2_HALF_SHAPES(X)                                                                                 \
   X(200, 1, 11, 1, 40, 10, 64)                                                                                \
@@ -1311,7 +1399,29 @@ static bool v2_fits(const dmf_shape& s) {
   return v2_matches<Sh>(s) && V2<Sh, true, HF>::lds_bytes(s.K) <= 160 * 1024;
 }
 
+template <class Sh>
+static hipError_t launch_v2_attn(int mode, const KArgs& a, hipStream_t st) {
+  const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
+  if (grid <= 0) return hipSuccess;
+  const bool gather = a.in.mode == 1;
+  if (mode == MODE_TOKENS) {
+    const int bytes = (V2<Sh, false, false>::FIXED + 2 * 128 * 72 / 2) * 4;      // + the bf16 token staging
+    if (bytes > 160 * 1024) return hipErrorInvalidValue;
+    return gather ? launch_v2_inst<Sh, MODE_TOKENS, 1, false>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_TOKENS, 0, false>(a, grid, bytes, st);
+  }
+  const int bytes = V2<Sh, true, false>::lds_bytes(a.K);
+  if (bytes > 160 * 1024) return hipErrorInvalidValue;
+  return gather ? launch_v2_inst<Sh, MODE_DENSE, 1, false>(a, grid, bytes, st) : launch_v2_inst<Sh, MODE_DENSE, 0, false>(a, grid, bytes, st);
+}
+
 int patch_v2_supported(const dmf_shape& s, int mode, int half) {
+  if (mode == MODE_TOKENS || mode == MODE_DENSE) {       // launches of the attention network (shape->attention is set)
+    if (half || s.K < 1 || s.K > KMAX) return 0;
+#define X(C, C2, P, S, F, G, H) if (v2_fits<Shape<C, C2, P, S, F, G, H>>(s)) return 1;
+    DMF_V2_ATTN_SHAPES(X)
+#undef X
+    return 0;
+  }
   if (mode != MODE_FWD && mode != MODE_TRAIN && mode != MODE_BWD && mode != MODE_UNIT) return 0;
   if (s.K < 1 || s.K > KMAX || s.attention) return 0;
   if (half) {
@@ -1338,6 +1448,12 @@ const char* patch_v2_shape_list() {
 }
 
 hipError_t patch_v2_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
+  if (mode == MODE_TOKENS || mode == MODE_DENSE) {
+#define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2_attn<Shape<C, C2, P, S, F, G, H>>(mode, a, st);
+    DMF_V2_ATTN_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+  }
   if (a.in.half) {
 #define X(C, C2, P, S, F, G, H) if (v2_matches<Shape<C, C2, P, S, F, G, H>>(s)) return launch_v2<Shape<C, C2, P, S, F, G, H>, true>(mode, a, st);
     DMF_V2_HALF_SHAPES(X)
