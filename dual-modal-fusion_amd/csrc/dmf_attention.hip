@@ -40,6 +40,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bfs;
 
 // Diagnostic build only (-DDMF_STAMPS, tools/attn_phase_profile.py): clock stamps of wave 0 along one patch.
+// Accumulation of a weight gradient in the workgroup's slab row (global memory) over the patches the workgroup walks: the
+// first patch stores, later ones add with a no-return float atomic.  Every element has ONE owning lane, so the sum order is
+// the program order of that lane (deterministic) — the atomic is used because it needs no load: `*p = *p + v` stalls the
+// wave for a global round trip in the middle of the backward, and every barrier behind it then waits for that wave.
+__device__ __forceinline__ void slab_acc(float* p, bool first, float v) {
+  if (first) *p = v;
+  else __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)p, v);
+}
+
 #ifdef DMF_STAMPS
 __device__ unsigned long long* g_astamps = nullptr;
 #define ASTAMP() do { if (threadIdx.x == 0 && g_astamps != nullptr && sidx < 64) g_astamps[(size_t)blockIdx.x * 64 + sidx] = clock64(); ++sidx; } while (0)
@@ -517,7 +526,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       const int e = tid + NT * i;
       if (e < F * E) {
         const float v = sDz[e / E] * sOb[e % E];
-        slab[(size_t)3 * E * F + e] = first ? v : slab[(size_t)3 * E * F + e] + v;
+        slab_acc(slab + (size_t)3 * E * F + e, first, v);
       }
     }
     __syncthreads();
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* p = slab + (size_t)(h * DH + 16 * wmt + 4 * g + r) * F + 16 * wnt + col;
-            *p = first ? acc[r] : *p + acc[r];
+            slab_acc(p, first, acc[r]);
           }
         }
       }
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float* p = slab + (size_t)E * F + (size_t)(h * DH + 16 * wmt + 4 * g + r) * F + 16 * wnt + col;
-            *p = first ? acc[r] : *p + acc[r];
+            slab_acc(p, first, acc[r]);
           }
         }
       }
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
           for (int q = 0; q < 8; ++q) bb += sCw[q * T + f];
           const float v = sU[h * DH + e / F] * bb;
-          *p = first ? v : *p + v;
+          slab_acc(p, first, v);
         }
       }
     }
