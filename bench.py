@@ -267,7 +267,7 @@ def main():
     value = world * B * K_steps / dt
 
     # ---- instrumented pass: mean duration of the dominant kernel, HIP events on the launch stream
-    n_inst = min(K_steps, 200)
+    n_inst = min(max(K_steps, 100), 200, plan_steps)     # (at least 100 launches, however short the timed region was)
     alg_patch = 2 * ((2 if args.half else 4) * P * P * C + 4 * (S * P) * (S * P) * C2)     # --half: the primary bands are 2 bytes
     kern_ms = None
     if rank == 0 or world > 1:
