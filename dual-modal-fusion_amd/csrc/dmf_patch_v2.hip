@@ -3,7 +3,7 @@
 // Replaces (reference): `output = self.cur_model(data1, data2)`, `loss = self.loss(output, target.long())`,
 // `loss.backward()` — solver/mainsolver.py:52-54 — and the eval forward + argmax (mainsolver.py:109,139,169-170).
 // Arithmetic: oracle/gmfnet_ref.py.  Same inputs, outputs and workspace contract as dmf_patch_kernel.hip (which
-// stays the generic kernel: S > 1, misaligned band groups, 16-row patches, token / dense modes).
+// stays the generic kernel for what this one has no instance of: misaligned band groups, K too large for its LDS budget).
 //
 // Measured facts this design is built on (tools/valu_rate.hip, tools/phase_profile_v2.py on MI355X):
 //   * A SIMD issues one vector instruction per ~3.2 (v_fmac) to ~4.9 (DPP, packed) cycles however many waves it hosts,
@@ -20,17 +20,22 @@
 // Sums over a channel's rows stop at QUAD level (two quad_perm DPP steps): a 12-lane segment straddles the 16-lane DPP
 // rows, so the NQ quad partials are kept apart (pooled features, slab row copies) and added by whoever consumes them.
 //
-// Flow per patch:
-//   gather   all waves issue the window's 1-KiB LDS-DMA pieces (buffer form; per-lane source offsets from a table built
-//            once); the aux row of a lane was loaded global -> registers just before
-//   aux      lift_b + spat_b forward AND backward for a UNIT upstream gradient, under the gather (tables through LDS
-//            reads the compiler cannot see; see hidden_read)
+// Flow per patch (gather mode, first patch of a workgroup; DESIGN.md section 4 has the measured timeline):
+//   entry    conv part of theta + pooling profile -> LDS by LDS-DMA, no wait; the first coordinates are requested first
+//   gather   as soon as the coordinates are known: aux image piece + the FIRST TWO window pieces of every wave, then a counted
+//            wait for what the wave issued before them (tables, aux piece) and barrier X; the other pieces leave from inside
+//            the aux phase (one per spat_b output column) — issuing is back-pressured, the aux arithmetic is not
+//   aux      lift_b + spat_b forward AND backward for a UNIT upstream gradient, under the gather (tables and aux rows through
+//            LDS reads the compiler cannot see; see hidden_read)
 //   barrier W  window complete
-//   primary  spec_a (packed FMAs, weights in registers, x from the group's LDS slice), spat_a forward + unit backward
-//   barrier 1  pooled features complete -> the head wave runs fc1 / fc2 / softmax-CE / dh while the conv waves
-//            form the unit spec_a weight gradient from the still-resident window
-//   barrier 2  dh complete -> every quad forms dz of its channel, scales its unit gradients and adds them to its copy of
-//            the workgroup's slab row (LDS); the row leaves in one coalesced pass at the end of the kernel
+//   primary  spec_a (packed FMAs, weights in registers, x from the group's LDS slice), spat_a forward
+//   barrier 1  pooled features complete -> the head wave runs fc1 / fc2 / softmax-CE / dh while the conv waves do spat_a's
+//            unit backward and form the unit spec_a weight gradient from the still-resident window
+//   barrier 2  dh complete -> dz of every feature by 4 lanes, barrier 3, one coalesced scaled copy-out of the slab row
+// Later patches of a workgroup (batch > 256) load the lane's aux row straight into registers and skip barrier X.
+// Variants compiled from the same body: HF (fp16 scene, fp16 spec_a operands), S = 4 (aux at 4x the resolution: aux patch
+// image in LDS, bank-rotated rows), MODE_UNIT (per-patch unit gradients for batch-coupled losses), MODE_TOKENS / MODE_DENSE
+// (the two conv launches of the attention network's step).
 // The network is piecewise linear and channel f reaches the head only through the pooled scalars z_a[f], z_b[f]: that is
 // what makes the unit-gradient backward (scaled by dL/dz[f] at the very end) exact.
 #include <hip/hip_runtime.h>
