@@ -186,6 +186,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float* theta, const float* gr
   if (cursor_dev != nullptr && p == 0) *cursor_dev += 1;
 }
 
+// ------------------------------------------------------------------------------ the reference's other two optimisers
+// torch.optim.SGD(lr, momentum) (dampening 0, no Nesterov, no weight decay): buf = g on the first step, else m buf + g;
+// p -= lr buf.  torch.optim.RMSprop(lr, alpha) (eps 1e-8, momentum 0, not centred): sq = alpha sq + (1 - alpha) g g;
+// p -= lr g / (sqrt(sq) + eps).   (utils/utils.py:13-16)
+__global__ __launch_bounds__(256) void sgd_kernel(float* theta, const float* grad, float* buf, int64_t n, float lr, float momentum,
+                                                  float grad_scale, const int32_t* step_dev, int32_t step, int32_t* cursor_dev) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int st = step_dev != nullptr ? *step_dev : step;
+  if (p < n) {
+    const float g = grad[p] * grad_scale;
+    float b = g;
+    if (momentum != 0.f) { b = st <= 1 ? g : momentum * buf[p] + g; buf[p] = b; }
+    theta[p] -= lr * b;
+  }
+  if (cursor_dev != nullptr && p == 0) *cursor_dev += 1;
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* theta, const float* grad, float* sq, int64_t n, float lr, float alpha,
+                                                      float eps, float grad_scale, int32_t* cursor_dev) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < n) {
+    const float g = grad[p] * grad_scale;
+    const float s = alpha * sq[p] + (1.f - alpha) * g * g;
+    sq[p] = s;
+    theta[p] -= lr * (g / (sqrtf(s) + eps));
+  }
+  if (cursor_dev != nullptr && p == 0) *cursor_dev += 1;
+}
+
 // ------------------------------------------------------------------------------ dynamic loss scaling (GradScaler's role)
 // state: [0] scale  [1] growth tracker  [2] found_inf  [3] skipped steps  [4] ticket (int bits)
 __global__ __launch_bounds__(256) void unscale_check_kernel(float* grad, int64_t n, float grad_scale, float* state) {
@@ -718,6 +747,24 @@ int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      theta, grad, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, adam_step_dev, cursor_dev);
   return check(hipGetLastError(), "adam launch");
+}
+
+int32_t dmf_sgd_step(float* theta, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                     int32_t step, float grad_scale, const int32_t* step_dev, int32_t* cursor_dev, void* stream) {
+  if (theta == nullptr || grad == nullptr || (momentum != 0.f && momentum_buf == nullptr)) return fail("%s", "null argument");
+  if (n <= 0 || (step < 1 && step_dev == nullptr)) return fail("%s", "n and step must be positive");
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), theta, grad,
+                     momentum_buf, n, lr, momentum, grad_scale, step_dev, step, cursor_dev);
+  return check(hipGetLastError(), "sgd launch");
+}
+
+int32_t dmf_rmsprop_step(float* theta, const float* grad, float* square_avg, int64_t n, float lr, float alpha, float eps,
+                         float grad_scale, int32_t* cursor_dev, void* stream) {
+  if (theta == nullptr || grad == nullptr || square_avg == nullptr) return fail("%s", "null argument");
+  if (n <= 0) return fail("%s", "n must be positive");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), theta,
+                     grad, square_avg, n, lr, alpha, eps, grad_scale, cursor_dev);
+  return check(hipGetLastError(), "rmsprop launch");
 }
 
 int32_t dmf_qua_loss_scaled(const float* logits, int32_t bs, int32_t K, const int32_t* labels, const int32_t* cursor,

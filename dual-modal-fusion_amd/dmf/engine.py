@@ -57,7 +57,13 @@ class LossScaler:
 
 
 class TrainEngine:
-    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm=None, scaler=None):
+    def __init__(self, net, scene, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm=None, scaler=None,
+                 optimizer='ADAM', momentum=0.0, alpha=0.99):
+        """optimizer: 'ADAM' (fused into the reduce launch), or the reference's other two (utils/utils.py:13-16) — 'SGD'
+        (`momentum`) and 'RMSprop' (`alpha`, eps 1e-8) — as a third launch on the flat gradient."""
+        if optimizer not in ('ADAM', 'SGD', 'RMSprop'):
+            raise lib.DmfError('optimizer %r is not one of ADAM, SGD, RMSprop' % (optimizer,))
+        self.optim, self.momentum, self.alpha = optimizer, float(momentum), float(alpha)
         self.net, self.scene, self.B = net, scene, int(batch)
         self.shape = net.shape
         lib.shape_supported(self.shape)
@@ -66,6 +72,8 @@ class TrainEngine:
         self.scaler = scaler
         if scaler is not None and (comm is not None or self.shape.attention):
             raise lib.DmfError('loss scaling: late-fusion net, single GPU or RCCL data parallel (not the xgmi exchange)')
+        if optimizer != 'ADAM' and (comm is not None or scaler is not None):
+            raise lib.DmfError('%s: single GPU or RCCL data parallel, no loss scaler (the fused exchange and the scaler step are ADAM)' % optimizer)
         self.lr, self.b1, self.b2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         dev = scene.device
         self.theta = net.flat_parameters()
@@ -123,6 +131,29 @@ class TrainEngine:
         if (self.comm is not None or self.scaler is not None) and dev_step is None:
             dev_step = self.dev_step                     # the exchange numbers its rounds by the device step count; with a
                                                          # loss scaler skipped steps make the device count the only true one
+        if self.optim != 'ADAM':
+            # forward + loss + backward, flat gradient [all-reduce], then the optimiser's own launch; m holds its one state
+            # vector (SGD: momentum buffer, RMSprop: running mean of squares)
+            if dev_step is None:
+                dev_step = self.dev_step                 # (SGD's first step is told by the device count: the patch kernel advances it)
+            if self.shape.attention:
+                lib.train_attn_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, None, 1.0 / nB, self.logits, self.loss,
+                                       self.ws, self.attn_ws, adam_step_dev=dev_step)
+            else:
+                lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
+                                  adam_step_dev=dev_step)
+            lib.grad_reduce(self.shape, nB, self.ws, self.grad)
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if loss_hist is not None:
+                loss_hist.scatter_(0, dev_cursor.long(), self.loss[:nB].mean().reshape(1))
+            if self.optim == 'SGD':
+                lib.sgd_step(theta, self.grad, self.m, self.lr, self.momentum, self.step_count, grad_scale=1.0 / self.world,
+                             step_dev=dev_step, cursor_dev=dev_cursor)
+            else:
+                lib.rmsprop_step(theta, self.grad, self.m, self.lr, self.alpha, grad_scale=1.0 / self.world, cursor_dev=dev_cursor)
+            return
         if self.scaler is not None:
             # scaler.scale(loss).backward() -> [all-reduce] -> scaler.unscale_ + scaler.step(opt) + scaler.update()
             sc = self.scaler
@@ -187,8 +218,8 @@ class TrainEngine:
             self.graph = None
         self.dev_cursor.zero_()
         self.host_cursor = 0
-        if self.scaler is None:                    # (with a scaler the device count is authoritative: skipped steps)
-            self.dev_step.fill_(self.step_count)
+        if self.scaler is None and self.optim == 'ADAM':   # (with a scaler the device count is authoritative: skipped steps;
+            self.dev_step.fill_(self.step_count)           #  the other optimisers always step by the device count)
         self.plan_steps = n
         return n
 
@@ -260,7 +291,7 @@ class TrainEngine:
         self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
 
     def _hparams(self):
-        return (self.lr, self.b1, self.b2, self.eps) + (self.scaler.hparams() if self.scaler is not None else ())
+        return (self.lr, self.b1, self.b2, self.eps, self.momentum, self.alpha) + (self.scaler.hparams() if self.scaler is not None else ())
 
     def mean_losses(self):
         """Per-step mean CE of the plan steps run so far (one D2H copy)."""

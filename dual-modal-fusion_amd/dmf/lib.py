@@ -68,6 +68,8 @@ def _load():
         'dmf_backward_unit': (i32, [SP, i32, vp, vp, vp, vp]),
         'dmf_grad_reduce': (i32, [SP, i32, vp, vp, vp]),
         'dmf_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp]),
+        'dmf_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, i32, f32, vp, vp, vp]),
+        'dmf_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
         'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
         'dmf_xgmi_sizes': (i32, [i64, i32, C.POINTER(i64), C.POINTER(i64)]),
         'dmf_xgmi_alloc': (i32, [i64, C.POINTER(vp)]),
@@ -276,6 +278,16 @@ def grad_reduce(shape, B, ws, grad):
 def adam_step(theta, grad, m, v, lr, b1, b2, eps, step, grad_scale=1.0, adam_step_dev=None, cursor_dev=None):
     check(_lib.dmf_adam_step(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), lr, b1, b2, eps, step,
                              grad_scale, _ptr(adam_step_dev), _ptr(cursor_dev), _stream()))
+
+
+def sgd_step(theta, grad, buf, lr, momentum, step, grad_scale=1.0, step_dev=None, cursor_dev=None):
+    check(_lib.dmf_sgd_step(_ptr(theta), _ptr(grad), _ptr(buf), theta.numel(), lr, momentum, step, grad_scale, _ptr(step_dev),
+                            _ptr(cursor_dev), _stream()))
+
+
+def rmsprop_step(theta, grad, sq, lr, alpha, eps=1e-8, grad_scale=1.0, cursor_dev=None):
+    check(_lib.dmf_rmsprop_step(_ptr(theta), _ptr(grad), _ptr(sq), theta.numel(), lr, alpha, eps, grad_scale, _ptr(cursor_dev),
+                                _stream()))
 
 
 def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step, adam_step_dev=None, cursor_dev=None,

@@ -28,7 +28,7 @@ from PIL import Image
 from tqdm import tqdm
 
 from solver.basesolver import BaseSolver
-from utils.utils import adam_hparams, epoch_lr, make_loss, make_optimizer, make_scheduler, save_checkpoint
+from utils.utils import epoch_hparams, make_loss, optim_hparams, make_optimizer, make_scheduler, save_checkpoint
 
 
 class Solver(BaseSolver):
@@ -117,16 +117,23 @@ class Solver(BaseSolver):
         from dmf.engine import EvalEngine, TrainEngine
         if self.cfg['schedule']['loss'] != 'Criterion':
             raise ValueError('the fused HIP step implements the Criterion (cross-entropy) loss')
-        lr, betas, eps = adam_hparams(self.cfg)
+        hp = optim_hparams(self.cfg)                             # ADAM (fused), SGD or RMSprop (utils/utils.py:10-16)
         if self.cfg['batchsize'] % self.world:
             raise ValueError('batchsize %d is not divisible by the %d ranks' % (self.cfg['batchsize'], self.world))
-        self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'] // self.world, lr=lr, betas=betas, eps=eps,
-                                  process_group=self.process_group, comm=self.comm)
+        self.engine = TrainEngine(self.cur_model, self.scene, self.cfg['batchsize'] // self.world, lr=hp['lr'], betas=hp['betas'],
+                                  eps=hp['eps'], process_group=self.process_group,
+                                  comm=self.comm if hp['optimizer'] == 'ADAM' else None, optimizer=hp['optimizer'],
+                                  momentum=hp.get('momentum', 0.0), alpha=hp.get('alpha', 0.99))
         self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize'] // self.world
-        eng.lr = epoch_lr(self.cfg, self.epoch)
+        hp = epoch_hparams(self.cfg, self.epoch)              # lr (and, under OneCycleLR, beta1 / momentum) of this epoch
+        eng.lr = float(hp['lr'])
+        if 'betas' in hp:
+            eng.b1, eng.b2 = float(hp['betas'][0]), float(hp['betas'][1])
+        if eng.optim == 'SGD':
+            eng.momentum = float(hp['momentum'])
         batches = [self._xy_labels(b) for b in self.train_index_loader]      # the epoch's shuffled coordinates
         if self.world > 1:                                                   # this rank's contiguous shard of every batch
             cut = []

@@ -26,7 +26,7 @@ from PIL import Image
 from function.function import data_padding, data_show, split_data_old
 from solver.mainsolver import Solver
 from train.dataset import dataset_qua_dqtl
-from utils.utils import adam_hparams, epoch_lr
+from utils.utils import adam_hparams, epoch_hparams
 
 
 class toStageSolver(Solver):
@@ -84,7 +84,8 @@ class toStageSolver(Solver):
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize']
-        eng.lr = epoch_lr(self.cfg, self.epoch)
+        hp = epoch_hparams(self.cfg, self.epoch)              # lr (and, under OneCycleLR, beta1) of this epoch
+        eng.lr, eng.b1, eng.b2 = float(hp['lr']), float(hp['betas'][0]), float(hp['betas'][1])
         batches = [self._xy_labels(b) for b in self.train_index_loader]
         full = [b for b in batches if b[0].shape[0] == B]
         losses = []

@@ -5,7 +5,7 @@ The three factories return the torch objects the reference builds from the same 
 scheduler kinds keep the reference's constants.  Here they are lookup tables of small constructors rather than
 if-chains.  They serve the drop-in path (reference-style loop -> `model.gmfnet.Net` -> autograd); the resident-scene
 fast path (dmf/engine.py) applies the same ADAM update inside `dmf_grad_reduce_adam` and takes only the hyper-parameters
-from here (`adam_hparams`, `epoch_lr`).  Checkpoints keep the reference's layout (:82-111): `{'state_dict', 'optimizer'}`.
+from here (`adam_hparams`, `epoch_hparams`: whatever scheduler kind is configured).  Checkpoints keep the reference's layout (:82-111): `{'state_dict', 'optimizer'}`.
 """
 import os
 import random
@@ -84,6 +84,20 @@ def make_scheduler(optimizer, cfg):
     return _pick(_SCHEDULERS, s['scheduler'], 'scheduler')(optimizer, s, cfg)
 
 
+def optim_hparams(cfg):
+    """What the resident-scene engine needs to reproduce make_optimizer(cfg, ...): kind + the constructor arguments the
+    reference passes (ADAM: lr; SGD: lr, momentum; RMSprop: lr, alpha — utils/utils.py:10-16), torch defaults otherwise."""
+    s = cfg['schedule']
+    kind = s['optimizer']
+    _pick(_OPTIMIZERS, kind, 'optimizer')
+    out = {'optimizer': kind, 'lr': float(s['lr']), 'betas': _ADAM_DEFAULTS[0], 'eps': _ADAM_DEFAULTS[1]}
+    if kind == 'SGD':
+        out['momentum'] = float(s['momentum'])
+    if kind == 'RMSprop':
+        out['alpha'] = float(s['alpha'])
+    return out
+
+
 def adam_hparams(cfg):
     """(lr, betas, eps) of the ADAM the reference constructs: lr from cfg, torch defaults otherwise."""
     if cfg['schedule']['optimizer'] != 'ADAM':
@@ -91,15 +105,49 @@ def adam_hparams(cfg):
     return (float(cfg['schedule']['lr']),) + _ADAM_DEFAULTS
 
 
+class _Schedule:
+    """The per-epoch hyper-parameters the reference's own scheduler object would give its optimiser.
+
+    The fused step takes lr / betas as launch arguments, so instead of re-deriving each of the eight scheduler kinds in
+    closed form, the SAME torch scheduler (make_scheduler) is driven on a one-element dummy optimiser (make_optimizer: the
+    same class and defaults) and its parameter group is read after every `scheduler.step()` — exactly the sequence the
+    reference sees (mainsolver.py:60: one step per epoch).  OneCycleLR also cycles ADAM's beta1; that comes along."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.param = torch.nn.Parameter(torch.zeros(1))
+        self.opt = make_optimizer(cfg, [self.param])
+        self.sched = make_scheduler(self.opt, cfg)
+        self.seq = [self._group()]
+
+    def _group(self):
+        g = self.opt.param_groups[0]
+        return {k: (tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items() if k != 'params'}
+
+    def at(self, epoch):
+        while len(self.seq) <= epoch:
+            if self.sched is not None:
+                self.opt.step()                   # (keeps torch's "scheduler before optimizer" warning quiet; the gradient is None)
+                self.sched.step()
+            self.seq.append(self._group())
+        return self.seq[epoch]
+
+
+_SCHEDULES = {}
+
+
+def epoch_hparams(cfg, epoch):
+    """Optimiser parameter group (lr, betas, ...) in force during epoch `epoch` (0-based), any scheduler kind."""
+    key = id(cfg)
+    sch = _SCHEDULES.get(key)
+    if sch is None or sch.cfg is not cfg:
+        sch = _SCHEDULES[key] = _Schedule(cfg)
+    return sch.at(epoch)
+
+
 def epoch_lr(cfg, epoch):
-    """Learning rate after `epoch` scheduler steps, for the fused step (ExponentialLR only; the other kinds run through
-    the torch optimiser of the drop-in path)."""
-    s = cfg['schedule']
-    if not s['if_scheduler']:
-        return float(s['lr'])
-    if s['scheduler'] != 'ExponentialLR':
-        raise ValueError('the fused HIP step supports ExponentialLR only; got %s' % s['scheduler'])
-    return float(s['lr']) * 0.98 ** epoch
+    """Learning rate after `epoch` scheduler steps, for the fused step (every scheduler kind of make_scheduler)."""
+    return float(epoch_hparams(cfg, epoch)['lr'])
 
 
 # ---------------------------------------------------------------------------------------------- checkpoints

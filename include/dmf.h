@@ -188,6 +188,15 @@ int32_t dmf_adam_step(float* theta, const float* grad, float* m, float* v, int64
 /* adam_step_dev (may be NULL): when given, the step count is read from the device instead of `step`.
  * cursor_dev (may be NULL): device int advanced by one (the epoch-plan cursor of dmf_input). */
 
+/* The reference's other two optimisers (utils/utils.py:13-16), on the flat gradient of dmf_grad_reduce:
+ * `torch.optim.SGD(params, lr, momentum)` — momentum_buf [n] may be NULL when momentum == 0; step (or *step_dev) == 1 marks the
+ * first step, where torch initialises the buffer with the gradient — and `torch.optim.RMSprop(params, lr, alpha)` (eps 1e-8
+ * is torch's default; square_avg [n] starts at zero).  grad_scale, cursor_dev as in dmf_adam_step. */
+int32_t dmf_sgd_step(float* theta, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                     int32_t step, float grad_scale, const int32_t* step_dev, int32_t* cursor_dev, void* stream);
+int32_t dmf_rmsprop_step(float* theta, const float* grad, float* square_avg, int64_t n, float lr, float alpha, float eps,
+                         float grad_scale, int32_t* cursor_dev, void* stream);
+
 /* dmf_grad_reduce + dmf_adam_step in one launch (single-GPU step). grad may be NULL. */
 int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* workspace,
                              float* theta, float* m, float* v, float* grad,

@@ -292,3 +292,42 @@ def test_stage2_with_scaler_and_half_scene():
     for k, v in hip1.state_dict().items():
         # (six Adam steps: an element whose gradient is ~ eps moves by up to lr per step whatever its size)
         assert_close(v, sd[k], 1e-4, 1e-4, 'stage-2 param %s (half scene, scaled)' % k)
+
+
+@pytest.mark.parametrize('kind', ['SGD', 'RMSprop'])
+@pytest.mark.parametrize('graph', [0, 3])
+def test_engine_with_the_references_other_optimizers(kind, graph):
+    """`make_optimizer` also offers SGD(lr, momentum) and RMSprop(lr, alpha) (utils/utils.py:13-16).  The resident-scene
+    engine runs them as a third launch on the flat gradient (dmf_sgd_step / dmf_rmsprop_step); trajectory against the
+    oracle net driven by torch's own optimiser on the same batches, eager and from a captured graph."""
+    from dmf.engine import Scene, TrainEngine
+    from test_gpu_parity import nets
+    name = 'tiny1'
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    n, B, H, W = 9, 16, 23, 19
+    A, Bm = scene(name, H, W, 31)
+    g = torch.Generator().manual_seed(32)
+    xy = torch.stack([torch.randint(0, H, (n * B,), generator=g), torch.randint(0, W, (n * B,), generator=g)], 1).int()
+    t = torch.randint(0, K, (n * B,), generator=g)
+    if kind == 'SGD':
+        opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9)
+        kw = dict(optimizer='SGD', momentum=0.9, lr=0.05)
+    else:
+        opt = torch.optim.RMSprop(ref.parameters(), lr=2e-3, alpha=0.9)
+        kw = dict(optimizer='RMSprop', alpha=0.9, lr=2e-3)
+    want = []
+    for s in range(n):
+        a, b = cut(A, Bm, xy[s * B:(s + 1) * B], P, S)
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(ref(a, b), t[s * B:(s + 1) * B])
+        loss.backward()
+        opt.step()
+        want.append(loss.item())
+    eng = TrainEngine(hip, Scene(A.numpy(), Bm.numpy(), 'cuda:0'), B, **kw)
+    eng.load_plan(xy, t)
+    eng.run_plan(n, steps_per_graph=graph)
+    assert np.allclose(eng.mean_losses().numpy(), want, atol=2e-5), (eng.mean_losses().numpy(), want)
+    sd = ref.state_dict()
+    for k, v in hip.state_dict().items():
+        assert_close(v, sd[k], 3e-5, 2e-4, '%s: param %s after %d steps' % (kind, k, n))

@@ -391,3 +391,28 @@ def test_testsolver_and_dataloaderx(golden_dir):
             list(DataLoaderX(Boom(), batch_size=1))
     finally:
         shutil.rmtree(tmp)
+
+
+def test_fast_path_hyperparameters_follow_every_scheduler_kind():
+    """utils.epoch_hparams: the per-epoch lr / betas the fused step is launched with = what the reference's own scheduler
+    object gives its optimiser after the same number of `scheduler.step()` calls (mainsolver.py:60), for all eight kinds
+    of make_scheduler (utils/utils.py:39-71) — OneCycleLR also cycles ADAM's beta1."""
+    import torch
+    from utils import utils as u
+    sched = {'optimizer': 'ADAM', 'lr': 1e-3, 'base_lr': 1e-4, 'momentum': 0.9, 'alpha': 0.9, 'if_scheduler': 1}
+    for kind in ('StepLR', 'LinearLR', 'CosineAnnealingLR', 'CyclicLR', 'OneCycleLR', 'ConstantLR', 'ChainedScheduler', 'ExponentialLR'):
+        cfg = {'epoch': 60, 'schedule': dict(sched, scheduler=kind)}
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = u.make_optimizer(cfg, [p])
+        sch = u.make_scheduler(opt, cfg)
+        for e in range(59):
+            hp = u.epoch_hparams(cfg, e)
+            assert hp['lr'] == opt.param_groups[0]['lr'] and tuple(hp['betas']) == tuple(opt.param_groups[0]['betas']), (kind, e)
+            opt.step(); sch.step()
+    cfg = {'epoch': 5, 'schedule': dict(sched, if_scheduler=0, scheduler='StepLR')}
+    assert [u.epoch_hparams(cfg, e)['lr'] for e in range(4)] == [1e-3] * 4
+    assert u.optim_hparams({'schedule': dict(sched, optimizer='SGD')}) == {'optimizer': 'SGD', 'lr': 1e-3, 'betas': (0.9, 0.999), 'eps': 1e-8, 'momentum': 0.9}
+    assert u.optim_hparams({'schedule': dict(sched, optimizer='RMSprop')})['alpha'] == 0.9
+    import pytest
+    with pytest.raises(ValueError):
+        u.optim_hparams({'schedule': dict(sched, optimizer='LBFGS')})
