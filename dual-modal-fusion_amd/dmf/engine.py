@@ -423,7 +423,13 @@ class QuaTrainEngine:
     Data parallel (process_group): every rank takes its shard of each batch; the logits of all ranks are gathered so that
     the batch-coupled loss is the GLOBAL batch's, the flat gradient is all-reduced (sum) and ADAM runs with 1/world."""
 
-    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, scaler=None):
+    def __init__(self, net, scene, bs, dqtl, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, scaler=None,
+                 optimizer='ADAM', momentum=0.0, alpha=0.99):
+        if optimizer not in ('ADAM', 'SGD', 'RMSprop'):
+            raise lib.DmfError('optimizer %r is not one of ADAM, SGD, RMSprop' % (optimizer,))
+        if optimizer != 'ADAM' and scaler is not None:
+            raise lib.DmfError('the loss-scaler step is ADAM')
+        self.optim, self.momentum, self.alpha = optimizer, float(momentum), float(alpha)
         if not net.arch.get('single_input'):
             raise lib.DmfError('stage 2 needs the single-input net (cfg["gmf"]["single_input"] = 1)')
         self.net, self.scene, self.bs = net, scene, int(bs)
@@ -458,7 +464,15 @@ class QuaTrainEngine:
         self.graph, self.graph_steps, self.graph_hparams = None, 0, None
 
     def _hparams(self):
-        return (self.lr, self.b1, self.b2, self.eps)
+        return (self.lr, self.b1, self.b2, self.eps, self.momentum, self.alpha)
+
+    def _optimizer_step(self, theta, grad_scale, dev_step, cursor):
+        """SGD / RMSprop on the flat gradient (utils/utils.py:13-16); m holds the optimiser's one state vector."""
+        if self.optim == 'SGD':
+            lib.sgd_step(theta, self.grad, self.m, self.lr, self.momentum, self.step_count, grad_scale=grad_scale,
+                         step_dev=dev_step, cursor_dev=cursor)
+        else:
+            lib.rmsprop_step(theta, self.grad, self.m, self.lr, self.alpha, grad_scale=grad_scale, cursor_dev=cursor)
 
     def _step(self, inp, bs, labels, cursor, loss_hist, dev_step=None):
         self.step_count += 1
@@ -489,7 +503,10 @@ class QuaTrainEngine:
             lib.backward_unit(self.shape, 4 * bs, theta, self.dlogits, self.ws)
         else:
             lib.backward_dlogits(self.shape, inp, theta, self.net.pool_w, self.dlogits, self.ws)
-        if self.world == 1:
+        if self.world == 1 and self.optim != 'ADAM':
+            lib.grad_reduce(self.shape, 4 * bs, self.ws, self.grad)
+            self._optimizer_step(theta, 1.0, dev_step if self.unit else None, cursor)
+        elif self.world == 1:
             lib.grad_reduce_adam(self.shape, 4 * bs, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
                                  self.step_count, adam_step_dev=dev_step if self.unit else None, cursor_dev=cursor)
         else:
@@ -502,8 +519,11 @@ class QuaTrainEngine:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg)
                 self.grad.copy_(g)
             # the loss kernel already divided by the GLOBAL batch (it saw all ranks' logits): the sum over ranks is the gradient
-            lib.adam_step(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count,
-                          grad_scale=1.0, cursor_dev=cursor)
+            if self.optim != 'ADAM':
+                self._optimizer_step(theta, 1.0, None, cursor)
+            else:
+                lib.adam_step(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count,
+                              grad_scale=1.0, cursor_dev=cursor)
 
     def _global_loss(self, bs, labels, cursor, loss_hist):
         """qua_loss couples all samples of the batch (six batch-mean KL terms): every rank evaluates it on the logits of

@@ -26,7 +26,7 @@ from PIL import Image
 from function.function import data_padding, data_show, split_data_old
 from solver.mainsolver import Solver
 from train.dataset import dataset_qua_dqtl
-from utils.utils import adam_hparams, epoch_hparams
+from utils.utils import epoch_hparams, optim_hparams
 
 
 class toStageSolver(Solver):
@@ -72,9 +72,10 @@ class toStageSolver(Solver):
         from dmf.engine import QuaTrainEngine
         if self.cfg['schedule']['loss'] != 'qua_loss':
             raise ValueError('stage 2 trains with schedule.loss: qua_loss')
-        lr, betas, eps = adam_hparams(self.cfg)
-        self.engine = QuaTrainEngine(self.cur_model, self.qua_scene, self.cfg['batchsize'], self.cfg['dqtl'], lr=lr,
-                                     betas=betas, eps=eps)
+        hp = optim_hparams(self.cfg)
+        self.engine = QuaTrainEngine(self.cur_model, self.qua_scene, self.cfg['batchsize'], self.cfg['dqtl'], lr=hp['lr'],
+                                     betas=hp['betas'], eps=hp['eps'], optimizer=hp['optimizer'],
+                                     momentum=hp.get('momentum', 0.0), alpha=hp.get('alpha', 0.99))
         self._make_eval_engine()
 
     def _make_eval_engine(self):
@@ -84,8 +85,12 @@ class toStageSolver(Solver):
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize']
-        hp = epoch_hparams(self.cfg, self.epoch)              # lr (and, under OneCycleLR, beta1) of this epoch
-        eng.lr, eng.b1, eng.b2 = float(hp['lr']), float(hp['betas'][0]), float(hp['betas'][1])
+        hp = epoch_hparams(self.cfg, self.epoch)              # lr (and, under OneCycleLR, beta1 / momentum) of this epoch
+        eng.lr = float(hp['lr'])
+        if 'betas' in hp:
+            eng.b1, eng.b2 = float(hp['betas'][0]), float(hp['betas'][1])
+        if eng.optim == 'SGD':
+            eng.momentum = float(hp['momentum'])
         batches = [self._xy_labels(b) for b in self.train_index_loader]
         full = [b for b in batches if b[0].shape[0] == B]
         losses = []

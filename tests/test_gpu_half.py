@@ -331,3 +331,43 @@ def test_engine_with_the_references_other_optimizers(kind, graph):
     sd = ref.state_dict()
     for k, v in hip.state_dict().items():
         assert_close(v, sd[k], 3e-5, 2e-4, '%s: param %s after %d steps' % (kind, k, n))
+
+
+@pytest.mark.parametrize('kind', ['SGD', 'RMSprop'])
+def test_stage2_engine_with_the_references_other_optimizers(kind):
+    """Stage 2 (qua_loss, unit-gradient step from a captured graph) under SGD / RMSprop against the oracle's loop
+    (oracle/solver_ref.py::qua_train_steps) driven by torch's optimiser."""
+    from dmf.engine import QuaScene, QuaTrainEngine
+    from oracle.solver_ref import qua_train_steps
+    from oracle.gmfnet_ref import Net as RefNet
+    from model.gmfnet import Net as HipNet
+    C, C2, P, S, K = SHAPES['qua']
+    cfg = make_cfg('qua')
+    cfg['gmf']['single_input'] = 1
+    torch.manual_seed(5)
+    ref = RefNet(cfg)
+    hip = HipNet(cfg); hip.load_state_dict(ref.state_dict()); hip = hip.cuda()
+    dqtl = {'alpha': 1.0, 'beta': 0.5, 'gamma': 0.5, 'epsilon': 1e-8, 'tao': 2.0}
+    g = torch.Generator().manual_seed(6)
+    H, W, bs, n = 20, 18, 8, 6
+    scenes = [(torch.rand(H + P - 1, W + P - 1, C, generator=g) - 0.2).numpy() for _ in range(4)]
+    xy = torch.stack([torch.randint(0, H, (n * bs,), generator=g), torch.randint(0, W, (n * bs,), generator=g)], 1).int()
+    lab = torch.randint(0, K, (n * bs,), generator=g)
+    if kind == 'SGD':
+        opt, kw = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9), dict(optimizer='SGD', lr=0.05, momentum=0.9)
+    else:
+        opt, kw = torch.optim.RMSprop(ref.parameters(), lr=2e-3, alpha=0.9), dict(optimizer='RMSprop', lr=2e-3, alpha=0.9)
+    want, _ = qua_train_steps(ref, scenes, xy.numpy(), lab.numpy(), bs, P, dqtl, optimizer=opt)
+    eng = QuaTrainEngine(hip, QuaScene(scenes, 'cuda:0'), bs, dqtl, **kw)
+    eng.load_plan(xy, lab)
+    eng.run_plan(n, steps_per_graph=3)
+    assert np.allclose(eng.losses().numpy(), want, atol=2e-5, rtol=1e-5), (eng.losses().numpy(), want)
+    sd = ref.state_dict()
+    for k, v in hip.state_dict().items():
+        if kind == 'RMSprop':
+            # RMSprop divides by sqrt(mean g^2) + 1e-8: an element whose gradient is rounding noise (|g| ~ eps) moves by up to lr per
+            # step whatever its size, like ADAM's dead channels (DESIGN.md section 9) — nearly all within tolerance, all within n lr
+            err = (v.cpu() - sd[k]).abs()
+            assert (err > 1e-4 + 2e-4 * sd[k].abs()).float().mean() < 0.03 and err.max() < n * 2e-3, (k, err.max())
+        else:
+            assert_close(v, sd[k], 1e-4, 2e-4, 'stage-2 %s: param %s' % (kind, k))
