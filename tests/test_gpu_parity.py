@@ -161,6 +161,38 @@ def test_train_fwd_bwd_grads(name, B):
         assert_close(g, want_g[k], 1e-5, 1e-4, 'grad %s [%s,B=%d]' % (k, name, B))
 
 
+@pytest.mark.parametrize('name,B', [('hsi', 700), ('qua', 1100), ('panms', 600)])
+def test_train_grads_three_and_more_patches_per_workgroup(name, B):
+    """Batches beyond 512: a workgroup walks three or more patches (the later-patch path of the v2 kernel — aux rows by direct
+    loads, no barrier X, slab row accumulated in place), in gather mode, against the oracle."""
+    from dmf import lib
+    from model.gmfnet import PARAM_ORDER
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    H, W = 23, 19
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(13)
+    xy = torch.stack([torch.randint(0, H, (B,), generator=g), torch.randint(0, W, (B,), generator=g)], 1).int()
+    t = torch.randint(0, K, (B,), generator=g)
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    b = torch.stack([Bm[S * x:S * x + S * P, S * y:S * y + S * P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    want_logits, want_loss, want_g = ref_grads(ref, a, b, t)
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    inp = lib.input_gather(hip.shape, Ad, Bd, xyd)
+    theta = hip.flat_parameters()
+    logits = torch.empty(B, K, device='cuda'); loss = torch.empty(B, device='cuda')
+    ws = hip.workspace(B)
+    lib.train_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t.int().cuda(), 1.0 / B, logits, loss, ws)
+    grad = torch.empty_like(theta)
+    lib.grad_reduce(hip.shape, B, ws, grad)
+    assert_close(logits, want_logits, 1e-5, 0, 'logits [%s, B=%d]' % (name, B))
+    assert abs(loss.mean().item() - want_loss) < 1e-5
+    off = hip._offsets
+    for i, k in enumerate(PARAM_ORDER):
+        gk = grad[off[i]:off[i] + want_g[k].numel()].view(want_g[k].shape)
+        assert_close(gk, want_g[k], 1e-5, 1e-4, 'grad %s [%s, B=%d]' % (k, name, B))
+
+
 @pytest.mark.parametrize('name', ['tiny', 'hsi', 'hsi32'])
 def test_train_gather_equals_patches(name):
     """Both input modes feed the same arithmetic: bit-identical logits, loss and gradient."""
