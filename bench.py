@@ -87,6 +87,26 @@ def make_plan(train, n_steps, B, seed):
     return np.concatenate(out)[:need]
 
 
+def prewarm(eng, net, args, ms):
+    """Device warm-up that touches NO training state: the forward + backward launch of plan batch 0 into the scratch
+    workspace, repeated for ~`ms` milliseconds (no optimiser launch, weights unchanged).  A freshly started process runs its
+    first kernels at ramping clocks; without this a short `--steps` run measures the ramp, not the step.  The W warm-up steps
+    the caller asked for follow as usual."""
+    from dmf import lib
+    B = eng.B
+    inp = lib.input_gather(eng.shape, eng.scene.A, eng.scene.B, eng.plan_xy[:B])
+    lab = eng.plan_labels[:B]
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(100):
+            if args.attention:
+                lib.train_attn_fwd_bwd(eng.shape, inp, eng.theta, net.pool_w, lab, None, 1.0 / B, eng.logits, eng.loss, eng.ws, eng.attn_ws)
+            else:
+                lib.train_fwd_bwd(eng.shape, inp, eng.theta, net.pool_w, lab, 1.0 / B, eng.logits, eng.loss, eng.ws)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
 def launch_label(spg, n_steps):
     """What run_plan(n_steps, spg) actually executes: it replays the captured graph while whole graphs fit, the rest eagerly."""
     if not spg:
@@ -210,6 +230,7 @@ def main():
     plan_idx = make_plan(train, plan_steps, B * world, seed=1)                 # global batches of world*B
     mine = plan_idx.reshape(plan_steps, world, B)[:, rank, :].reshape(-1)      # this rank's contiguous shard per step
     eng.load_plan(xy_tab[mine], lab_tab[mine])
+    prewarm_ms = prewarm(eng, net, args, 60.0)
     graphable = world == 1 or comm is not None                                 # RCCL path: eager launches
     spg = min(args.steps_per_graph, K_steps) if graphable else 0
 
@@ -351,6 +372,7 @@ def main():
         'config': {'workload': '%s; %dx%d patches, %d logits, batch %d per GPU, fused HIP fwd+loss+bwd+Adam'
                                % (CONFIGS[args.config]['name'], P, P, args.classes + 1, B),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch,
+                   'device_prewarm_ms': round(prewarm_ms, 1),
                    'allreduce': 'none' if world == 1 else ('xgmi one-shot, fused in the reduce+Adam launch' if comm is not None
                                                            else 'rccl all_reduce of one flat fp32 gradient')},
         'roofline': roof,
@@ -454,6 +476,13 @@ def main_stage2(args, dev):
     lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
     eng.load_plan(xy, lab)
     spg = min(args.steps_per_graph, K_steps) if eng.unit else 0
+    # device warm-up that touches no training state (see prewarm()): the dominant launch into the scratch workspace, ~60 ms
+    inp0 = lib.input_gather(eng.shape, scene.A, scene.B, eng.plan_xy[:4 * bs])
+    t_pw = time.perf_counter()
+    while (time.perf_counter() - t_pw) * 1e3 < 60.0:
+        for _ in range(50):
+            eng.time_dominant(inp0)
+        torch.cuda.synchronize()
     eng.run_plan(W_steps, spg)                  # (the warm-up replays the same graph: see main())
     launch, n_replays = launch_label(spg, K_steps)
     if n_replays and eng.graph is None:
