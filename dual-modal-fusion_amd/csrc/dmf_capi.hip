@@ -376,10 +376,10 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
     a.ws_dl = ws + w.dl;
   }
   // the wave-per-channel-block kernel where it is built for the shape; DMF_PATCH_V1=1 forces the generic kernel (A/B runs)
-  // (S > 1 on the v2 kernel: the aux patch image is fetched in 16-byte pieces — aux rows must be whole 16-byte units apart and
-  // start on one, which the padded scenes of this build always satisfy; anything else goes to the generic kernel)
-  const bool aux16 = s->S == 1 || in->mode != 1 || (((int64_t)in->WpB * s->C2) % 4 == 0 && (reinterpret_cast<uintptr_t>(in->sceneB) & 15) == 0);
-  if (in->half || (!force_v1() && aux16 && patch_v2_supported(*s, mode)))
+  // (S > 1 on the v2 kernel: the aux patch image is fetched in 16-byte LDS-DMA pieces whose source addresses are only
+  // dword aligned when the aux row pitch is not a multiple of 4 floats — the reference pads a 1024-wide PAN to 1087; the
+  // buffer loads take that: tests/test_gpu_parity.py::test_aux_scene_pitch_not_a_multiple_of_four)
+  if (in->half || (!force_v1() && patch_v2_supported(*s, mode)))
     return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel (v2) launch");
   return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }
@@ -562,8 +562,6 @@ int32_t dmf_forward_unit(const dmf_shape* s, const dmf_input* in, const float* t
   a.logits = logits;
   a.adam_step = adam_step_dev;
   a.K = s->K;
-  if (s->S > 1 && in->mode == 1 && ((((int64_t)in->WpB * s->C2) % 4) != 0 || (reinterpret_cast<uintptr_t>(in->sceneB) & 15) != 0))
-    return fail("%s", "unit-gradient step with S > 1: aux scene rows must start on and be whole 16-byte units apart");
   a.slab = ws + w.unit;          // MODE_UNIT: one row per patch
   a.ws_z = ws + w.z;
   a.ws_h = ws + w.h;

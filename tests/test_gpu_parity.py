@@ -193,6 +193,46 @@ def test_train_grads_three_and_more_patches_per_workgroup(name, B):
         assert_close(gk, want_g[k], 1e-5, 1e-4, 'grad %s [%s, B=%d]' % (k, name, B))
 
 
+@pytest.mark.parametrize('name', ['panms', 'tiny'])
+@pytest.mark.parametrize('extra', [1, 3])
+def test_aux_scene_pitch_not_a_multiple_of_four(name, extra):
+    """The reference pads the 2-D aux image by 4p - 1 (function.py:99-117): a 1024-wide PAN becomes 1087 wide, so the rows of the
+    resident aux scene are only 4-byte aligned.  The v2 kernel's 16-byte aux fetches must take that (forward, loss, gradients
+    against the oracle, gather mode, patches at the scene's far corner included)."""
+    from dmf import lib
+    from model.gmfnet import PARAM_ORDER
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    H, W, B = 23, 19, 150
+    g = torch.Generator().manual_seed(17)
+    A = torch.rand(H + P - 1, W + P - 1, C, generator=g)
+    Bm = torch.rand(S * (H + P - 1) + extra, S * (W + P - 1) + extra, C2, generator=g)      # pitch % 4 == extra
+    xy = torch.stack([torch.randint(0, H, (B,), generator=g), torch.randint(0, W, (B,), generator=g)], 1).int()
+    xy[0] = torch.tensor([H - 1, W - 1]); xy[1] = torch.tensor([0, 0])
+    t = torch.randint(0, K, (B,), generator=g)
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    b = torch.stack([Bm[S * x:S * x + S * P, S * y:S * y + S * P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    want_logits, want_loss, want_g = ref_grads(ref, a, b, t)
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    assert (Bd.shape[1] * C2) % 4 == extra
+    inp = lib.input_gather(hip.shape, Ad, Bd, xyd)
+    theta = hip.flat_parameters()
+    logits = torch.empty(B, K, device='cuda'); loss = torch.empty(B, device='cuda')
+    ws = hip.workspace(B)
+    lib.train_fwd_bwd(hip.shape, inp, theta, hip.pool_w, t.int().cuda(), 1.0 / B, logits, loss, ws)
+    grad = torch.empty_like(theta)
+    lib.grad_reduce(hip.shape, B, ws, grad)
+    assert_close(logits, want_logits, 1e-5, 0, 'logits [%s, pitch %% 4 = %d]' % (name, extra))
+    assert abs(loss.mean().item() - want_loss) < 1e-5
+    off = hip._offsets
+    for i, k in enumerate(PARAM_ORDER):
+        gk = grad[off[i]:off[i] + want_g[k].numel()].view(want_g[k].shape)
+        assert_close(gk, want_g[k], 1e-5, 1e-4, 'grad %s [%s, pitch %% 4 = %d]' % (k, name, extra))
+    fl = torch.empty(B, K, device='cuda')
+    lib.forward(hip.shape, inp, theta, hip.pool_w, fl)
+    assert_close(fl, want_logits, 1e-5, 0, 'eval logits [%s, pitch %% 4 = %d]' % (name, extra))
+
+
 @pytest.mark.parametrize('name', ['tiny', 'hsi', 'hsi32'])
 def test_train_gather_equals_patches(name):
     """Both input modes feed the same arithmetic: bit-identical logits, loss and gradient."""
