@@ -1263,7 +1263,10 @@ __global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a)
   constexpr int NE = (Sh::SLAB + 255) / 256;        // slab elements per thread
   __shared__ float sW1[H * W1S];
   __shared__ float sW2[KMAX * (H + 1)];
-  __shared__ float sDl[KMAX], sDh[H], sDz[F2 + 1];
+  // NPB patches of the workgroup per round (wave q <-> patch q for the head vectors): one set of barriers for four patches
+  constexpr int NPB = 4;
+  static_assert(H == 64 && KMAX == 64, "wave q handles the 64 hidden units / logits of patch q");
+  __shared__ float sDl[NPB][KMAX], sDh[NPB][H], sDz[NPB][F2 + 1];
   const int tid = threadIdx.x, K = a.K;
   for (int i = tid; i < H * F2; i += 256) sW1[(i / F2) * W1S + (i % F2)] = a.theta[Sh::oFc1w + i];
   for (int i = tid; i < K * H; i += 256) sW2[(i / H) * (H + 1) + (i % H)] = a.theta[Sh::oFc2w + i];
@@ -1271,7 +1274,7 @@ __global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a)
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int p = tid + 256 * e;
-    int v = F2;                                     // padding: multiplies with sDz[F2] = 0
+    int v = F2;                                     // padding: multiplies with sDz[.][F2] = 0
     if (p < Sh::oA1b) v = p / Cg;
     else if (p < Sh::oA2w) v = p - Sh::oA1b;
     else if (p < Sh::oA2b) v = (p - Sh::oA2w) / 9;
@@ -1285,39 +1288,46 @@ __global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a)
   float acc[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) acc[e] = 0.f;
-  if (tid == 0) sDz[F2] = 0.f;
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    float u[NE];                                    // this patch's unit row: issued before the head math
+  if (tid < NPB) sDz[tid][F2] = 0.f;
+  const int q = tid >> 6, j = tid & 63;             // this thread's patch slot and hidden unit / logit
+  for (int b0 = blockIdx.x; b0 < a.B; b0 += NPB * gridDim.x) {
+    float u[NPB][NE];                               // the unit rows of the round's patches: issued before the head math
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int p = tid + 256 * e;
-      u[e] = p < Sh::SLAB ? a.unit[(size_t)b * Sh::SLAB + p] : 0.f;
+    for (int r = 0; r < NPB; ++r) {
+      const int b = b0 + r * (int)gridDim.x;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int p = tid + 256 * e;
+        u[r][e] = (b < a.B && p < Sh::SLAB) ? a.unit[(size_t)b * Sh::SLAB + p] : 0.f;
+      }
     }
-    float hj = 0.f;
-    if (tid < KMAX) {
-      const float d = tid < K ? a.dlogits[(size_t)b * K + tid] : 0.f;
-      sDl[tid] = d;
-      a.ws_dl[(size_t)b * KMAX + tid] = d;
-    }
-    if (tid < H) hj = a.ws_h[(size_t)b * H + tid];
+    const int bq = b0 + q * (int)gridDim.x;
+    const bool on = bq < a.B;
+    const float d = (on && j < K) ? a.dlogits[(size_t)bq * K + j] : 0.f;
+    sDl[q][j] = d;
+    if (on) a.ws_dl[(size_t)bq * KMAX + j] = d;
+    const float hj = on ? a.ws_h[(size_t)bq * H + j] : 0.f;
     __syncthreads();
-    if (tid < H) {
-      float s = 0.f;
-      for (int k = 0; k < K; ++k) s = fmaf(sW2[k * (H + 1) + tid], sDl[k], s);
-      const float dh = hj > 0.f ? s : 0.f;
-      sDh[tid] = dh;
-      a.ws_dh[(size_t)b * H + tid] = dh;
+    {
+      float s_ = 0.f;
+      for (int k = 0; k < K; ++k) s_ = fmaf(sW2[k * (H + 1) + j], sDl[q][k], s_);
+      const float dh = hj > 0.f ? s_ : 0.f;
+      sDh[q][j] = dh;
+      if (on) a.ws_dh[(size_t)bq * H + j] = dh;
     }
     __syncthreads();
-    if (tid < F2) {
-      float s = 0.f;
+    for (int t = tid; t < NPB * F2; t += 256) {
+      const int r = t / F2, i = t - r * F2;
+      float s_ = 0.f;
 #pragma unroll 8
-      for (int j = 0; j < H; ++j) s = fmaf(sW1[j * W1S + tid], sDh[j], s);
-      sDz[tid] = s;
+      for (int jj = 0; jj < H; ++jj) s_ = fmaf(sW1[jj * W1S + i], sDh[r][jj], s_);
+      sDz[r][i] = s_;
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < NE; ++e) acc[e] = fmaf(sDz[ix[e]], u[e], acc[e]);
+    for (int r = 0; r < NPB; ++r)                   // (patches in ascending order: the summation order of a patch-by-patch loop)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[e] = fmaf(sDz[r][ix[e]], u[r][e], acc[e]);
     __syncthreads();
   }
 #pragma unroll
