@@ -116,13 +116,20 @@ __device__ __forceinline__ bf16x8 frag2(const bfs* M, int r0, int kA, int kB, in
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 // fragment of tokens[t][f] (k = f) gathered from the TRANSPOSED map MT[f][t]: row t = t0 + (lane&15)
+// Two transposed reads (ds_read_b64_tr_b16): per 16-lane group a block of 4 rows x 16 columns, lane 4q+p of the group
+// supplies the address of row q / columns 4p..4p+3 and lane i receives column i of the four rows.  EXEC must be all ones
+// (every call site is workgroup uniform); t0 is a multiple of 16 and RS of 4 (8-byte aligned addresses).
 template <int RS>
 __device__ __forceinline__ bf16x8 frag_t(const bfs* MT, int t0, int k0, int lane) {
-  const bfs* p = MT + (k0 + 8 * (lane >> 4)) * RS + t0 + (lane & 15);
-  bf16x8 v;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(__bf16, p[i * RS]);
-  return v;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  static_assert(RS % 4 == 0, "8-byte aligned rows");
+  const int i = lane & 15;
+  const bfs* p = MT + (k0 + 8 * (lane >> 4) + (i >> 2)) * RS + t0 + 4 * (i & 3);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * RS));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 // register operands from two C tiles
 __device__ __forceinline__ bf16x8 pack_bf(const f32x4& a, const f32x4& b) {
@@ -140,6 +147,10 @@ __device__ __forceinline__ void split_hl(const f32x4& a, const f32x4& b, bf16x8&
 // softmax arithmetic: exp(x) = 2^(x * log2 e) on the transcendental unit and a reciprocal instead of 32 divisions per
 // row; both are within ~1e-6 relative of expf / division, far below the bf16 rounding the probabilities get next
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// exp(s - m) as 2^(s * log2 e + nm) with nm = -m * log2 e formed once per row: one fused multiply-add per element
+// (pairs of them in one v_pk_fma_f32) instead of a subtraction and a multiplication
+constexpr float LOG2E = 1.44269504088896341f;
+__device__ __forceinline__ float fexp_nm(float s, float nm) { return __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E, nm)); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 }  // namespace at
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #define sOb AT_F(L::fOb)
 #define sObw AT_F(L::fObw)
 #define sDzw AT_F(L::fDzw)
-#define sSt AT_F(L::fSt)   /* per query t: {row max, 1 / row sum, abar_t, w_t} */
+#define sSt AT_F(L::fSt)   /* per query t: {-row max * log2 e, 1 / row sum, abar_t, w_t} */
 #define sA AT_F(L::fA)
 #define sCw AT_F(L::fCw)
 #define sC AT_F(L::fC)
@@ -322,17 +333,18 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         }
       mx = xrow_max(mx);
       float sum = 0.f;
+      const float nm = -mx * LOG2E;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[i][r] = fexp(s[i][r] - mx); sum += s[i][r]; }
+        for (int r = 0; r < 4; ++r) { s[i][r] = fexp_nm(s[i][r], nm); sum += s[i][r]; }
       sum = xrow_sum(sum);
       const float inv = frcp(sum);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[i][r] *= inv;
-      mx_out = mx; inv_out = inv;
+      mx_out = nm; inv_out = inv;                     // (the row statistic kept is nm = -max * log2 e)
     };
     // ------------------------------------------------------------------ tokens -> LDS, transposed [f][t]
     __syncthreads();
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float4 st = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r));
-            const float p = fexp(s[i][r] - st.x) * st.y;                             // P[t][j]
+            const float p = fexp_nm(s[i][r], st.x) * st.y;                           // P[t][j], as softmax_T forms it
             cpart = fmaf(bf2f((__bf16)p), st.w, cpart);                              // c_j += bf16(P)[t][j] w_t
             s[i][r] = keyok ? st.w * p * (aj - st.z) : 0.f;                          // w_t P[t][j] (a_j - abar_t)
           }
