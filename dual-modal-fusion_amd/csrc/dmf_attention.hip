@@ -143,6 +143,16 @@ __device__ __forceinline__ void split_hl(const f32x4& a, const f32x4& b, bf16x8&
     lo[i] = (__bf16)(a[i] - (float)ha); lo[4 + i] = (__bf16)(b[i] - (float)hb);
   }
 }
+// two floats -> one dword of two bf16 (a in the low half): ONE v_cvt_pk_bf16_f32 (element-wise casts of a 2-vector are
+// scalarised into two conversions); the halves of such a dword as floats again
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pk2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2)); }
+__device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ bfs lo_h(unsigned u) { return (bfs)(u & 0xffffu); }
+__device__ __forceinline__ bfs hi_h(unsigned u) { return (bfs)(u >> 16); }
 #define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 // softmax arithmetic: exp(x) = 2^(x * log2 e) on the transcendental unit and a reciprocal instead of 32 divisions per
 // row; both are within ~1e-6 relative of expf / division, far below the bf16 rounding the probabilities get next
@@ -305,17 +315,16 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       const int rb = 4 * g;
   #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        bfs qh[4], kh[4], vh[4];
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          qh[r] = f2bf(q[n][r] * scale); kh[r] = f2bf(k[n][r]); vh[r] = f2bf(v[n][r]);
-          sQ[(m0 + rb + r) * QS + 16 * n + col] = qh[r];
-          sK[(m0 + rb + r) * KS + 16 * n + col] = kh[r];
-        }
+        const unsigned q01 = pk2(q[n][0] * scale, q[n][1] * scale), q23 = pk2(q[n][2] * scale, q[n][3] * scale);
+        const unsigned k01 = pk2(k[n][0], k[n][1]), k23 = pk2(k[n][2], k[n][3]);
+        bfs* pq = sQ + (m0 + rb) * QS + 16 * n + col;
+        bfs* pk = sK + (m0 + rb) * KS + 16 * n + col;
+        pq[0 * QS] = lo_h(q01); pq[1 * QS] = hi_h(q01); pq[2 * QS] = lo_h(q23); pq[3 * QS] = hi_h(q23);
+        pk[0 * KS] = lo_h(k01); pk[1 * KS] = hi_h(k01); pk[2 * KS] = lo_h(k23); pk[3 * KS] = hi_h(k23);
         const int o = (16 * n + col) * VS + m0 + rb;     // 4 consecutive tokens of one feature: one 8-byte store
-        *reinterpret_cast<uint2*>(sQt + o) = make_uint2((uint32_t)qh[0] | ((uint32_t)qh[1] << 16), (uint32_t)qh[2] | ((uint32_t)qh[3] << 16));
-        *reinterpret_cast<uint2*>(sKt + o) = make_uint2((uint32_t)kh[0] | ((uint32_t)kh[1] << 16), (uint32_t)kh[2] | ((uint32_t)kh[3] << 16));
-        *reinterpret_cast<uint2*>(sVt + o) = make_uint2((uint32_t)vh[0] | ((uint32_t)vh[1] << 16), (uint32_t)vh[2] | ((uint32_t)vh[3] << 16));
+        *reinterpret_cast<uint2*>(sQt + o) = make_uint2(q01, q23);
+        *reinterpret_cast<uint2*>(sKt + o) = make_uint2(k01, k23);
+        *reinterpret_cast<uint2*>(sVt + o) = make_uint2(pk2(v[n][0], v[n][1]), pk2(v[n][2], v[n][3]));
       }
     };
     // P^T for the wave's queries: s[i][r] = P[t = tq][j = 16i + 4g + r]  (fp32, keys >= P2 masked)
@@ -395,14 +404,17 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
       for (int n = 0; n < 3; ++n) accO[n] = AT_MFMA(frag2<OS>(sWo, 16 * n, 0, 16, lane), ob, accO[n]);
       // obar_h[d] = sum_t w_t bf16(O)[t][d]: this wave's 16 tokens
-      if constexpr (TRAIN)
+      if constexpr (TRAIN) {
+        const u32x4 ow = __builtin_bit_cast(u32x4, ob);          // ob[4 mt + r] = bf16(o[mt][r]): word 2 mt + r / 2
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = row16_sum(wq * bf2f((__bf16)o[mt][r]));
-          if (col == 0) sObw[wave * E + h * DH + 16 * mt + 4 * g + r] = v;
-        }
+          for (int r = 0; r < 4; ++r) {
+            const unsigned w2 = ow[2 * mt + (r >> 1)];
+            const float v = row16_sum(wq * ((r & 1) ? hi_f(w2) : lo_f(w2)));
+            if (col == 0) sObw[wave * E + h * DH + 16 * mt + 4 * g + r] = v;
+          }
+      }
     }
     ASTAMP();                                        // 13
     // pooled correction za[f] += sum_t w_t (O Wo^T)[t][f]
@@ -625,15 +637,17 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
           accTa[n] = AT_MFMA(fw, hi, accTa[n]);
           accTa[n] = AT_MFMA(fw, lo, accTa[n]);
         }
-        // dq^T[d][t] -> LDS (hi / lo) for dWq
+        // dq^T[d][t] -> LDS (hi / lo) for dWq: the halves of the operand words just formed (element 4 mt + r; read as
+        // 32-bit words — extracting a __bf16 element of the packed vector was folded to element 0 by the compiler)
+        const u32x4 hw = __builtin_bit_cast(u32x4, hi), lw = __builtin_bit_cast(u32x4, lo);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int o = (16 * mt + 4 * g + r) * VS + tq;
-            const __bf16 vh = (__bf16)dq[mt][r];          // (scalars again: extracting hi[4*mt+r] from the packed
-            sDhi[o] = __builtin_bit_cast(bfs, vh);         //  operand vector is folded to element 0 by the compiler)
-            sDlo[o] = __builtin_bit_cast(bfs, (__bf16)(dq[mt][r] - (float)vh));
+            const unsigned wh = hw[2 * mt + (r >> 1)], wl = lw[2 * mt + (r >> 1)];
+            sDhi[o] = (r & 1) ? hi_h(wh) : lo_h(wh);
+            sDlo[o] = (r & 1) ? hi_h(wl) : lo_h(wl);
           }
       }
       ASTAMP();
@@ -683,11 +697,16 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float4 st = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r));
-            const float p = fexp_nm(s[i][r], st.x) * st.y;                           // P[t][j], as softmax_T forms it
-            cpart = fmaf(bf2f((__bf16)p), st.w, cpart);                              // c_j += bf16(P)[t][j] w_t
-            s[i][r] = keyok ? st.w * p * (aj - st.z) : 0.f;                          // w_t P[t][j] (a_j - abar_t)
+          for (int r = 0; r < 4; r += 2) {
+            const float4 st0 = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r));
+            const float4 st1 = *reinterpret_cast<const float4*>(sSt + 4 * (16 * i + 4 * g + r + 1));
+            const float p0 = fexp_nm(s[i][r], st0.x) * st0.y;                        // P[t][j], as softmax_T forms it
+            const float p1 = fexp_nm(s[i][r + 1], st1.x) * st1.y;
+            const unsigned pb = pk2(p0, p1);
+            cpart = fmaf(lo_f(pb), st0.w, cpart);                                    // c_j += bf16(P)[t][j] w_t
+            cpart = fmaf(hi_f(pb), st1.w, cpart);
+            s[i][r] = keyok ? st0.w * p0 * (aj - st0.z) : 0.f;                       // w_t P[t][j] (a_j - abar_t)
+            s[i][r + 1] = keyok ? st1.w * p1 * (aj - st1.z) : 0.f;
           }
         cpart = xrow_sum(cpart);                      // all 128 queries of this key: 32 in the lane, x 4 lane groups
         if (g == 0) sC[tq] = keyok ? cpart : 0.f;
@@ -713,15 +732,18 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       }
       ASTAMP();
       __syncthreads();                               // sync2: dWq products have read sD; c is complete
+      {
+        const u32x4 hw = __builtin_bit_cast(u32x4, khi), lw = __builtin_bit_cast(u32x4, klo);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int o = (16 * mt + 4 * g + r) * VS + tq;
-          const __bf16 vh = (__bf16)dk[mt][r];
-          sDhi[o] = __builtin_bit_cast(bfs, vh);
-          sDlo[o] = __builtin_bit_cast(bfs, (__bf16)(dk[mt][r] - (float)vh));
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int o = (16 * mt + 4 * g + r) * VS + tq;
+            const unsigned wh = hw[2 * mt + (r >> 1)], wl = lw[2 * mt + (r >> 1)];
+            sDhi[o] = (r & 1) ? hi_h(wh) : lo_h(wh);
+            sDlo[o] = (r & 1) ? hi_h(wl) : lo_h(wl);
+          }
+      }
       {                                              // bbar[f] = sum_j c_j bf16(Tb)[j][f]: thread <-> (f, 16 keys)
         const int f = tid & 63, part = tid >> 6;
         float s2 = 0.f;
