@@ -168,7 +168,10 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 template <class Sh, int E, int NH>
 struct AttnTrainLds {
   static constexpr int T = 128, FP = 64, DH = 32, FO = 48;
-  static constexpr int VS = 136, QS = 40, KS = 40, WS = 72, OS = 40;
+  // row strides in halves.  ds_read_b128 serves a wave in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...) over
+  // 64 banks: a [row][k] image read as fragments (lane = row, 16-byte chunk lane>>4) is conflict free when the row stride
+  // is an EVEN number of 16-byte slots that is not a multiple of 4 (QS, KS: 6; WS: 10) — 5 or 9 slots cost 2x per read
+  static constexpr int VS = 136, QS = 48, KS = 48, WS = 80, OS = 40;
   // halves
   static constexpr int oTaT = 0, oTbT = oTaT + FP * VS, oQ = oTbT + FP * VS, oK = oQ + T * QS, oQt = oK + T * KS,
                        oKt = oQt + DH * VS, oVt = oKt + DH * VS, oWq = oVt + DH * VS, oWk = oWq + DH * WS,
@@ -183,6 +186,7 @@ struct AttnTrainLds {
   static_assert(oWo + FO * OS - oWq == WPREP && WPREP % 8 == 0 && oWq % 8 == 0, "weights are one contiguous LDS block");
   static constexpr size_t BYTES = (size_t)HALVES * 2 + (size_t)FLOATS * 4;
   static_assert(HALVES % 8 == 0, "float region stays 16-byte aligned");
+  static_assert(BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
 // TRAIN = false: forward only (logits, argmax) — the inference / evaluation kernel of the attention network.
