@@ -199,6 +199,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
   constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, P2 = Sh::P2;
   constexpr int RSD = (Sh::P + 3) & ~3;               // row stride of the dense gradient maps (16-byte aligned rows)
   static_assert(E == NH * DH && F == 40 && F2 == 80 && H == 64 && P2 <= T, "attention geometry");
+  static_assert(H % 4 == 0 && F % 4 == 0 && 4 * F2 <= NT - 64 && 4 * E <= NT, "thread roles of the head backward");
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   // every LDS array is a constant offset from the dynamic-LDS symbol: no pointer variables that could be spilled as
   // generic 64-bit pointers (their accesses would become flat_* instead of ds_*)
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
   float* __restrict__ slab = a.aslab + (size_t)blockIdx.x * (4 * E * F);
   const int wmt = wave / 3, wnt = wave % 3;          // dWq / dWk tile of this wave (waves 0..5): d tile, f tile
   // head weights this thread needs (forward and backward) are patch invariant: fetched once per workgroup
-  float hw1[10], hw2[8], hwd[8], hwz[11], hwu[8], hb1, hb2;
+  float hw1[10], hw2[8], hwd[8], hwz[16], hwu[10], hb1, hb2;
   {
     const int j = tid0 >> 3, pp = tid0 & 7;                        // fc1: row j, columns pp + 8 m;  fc2: row k = j
 #pragma unroll
@@ -260,15 +261,16 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
     for (int m = 0; m < 8; ++m) hw2[m] = j < K ? th[a.oFc2w + (int64_t)j * H + pp + 8 * m] : 0.f;
     hb2 = j < K ? th[a.oFc2b + j] : 0.f;
-    const int jd = tid0 & 63, pd = tid0 >> 6;                      // dh: column jd, rows k = pd + 8 i
+    // the backward products keep the parts of one output in ADJACENT lanes (summed by DPP, no LDS round trip + barrier)
+    const int jd = tid0 >> 3, pd = tid0 & 7;                       // dh: column jd, rows k = pd + 8 i
 #pragma unroll
     for (int i = 0; i < 8; ++i) hwd[i] = (TRAIN && pd + 8 * i < K) ? th[a.oFc2w + (int64_t)(pd + 8 * i) * H + jd] : 0.f;
-    const int pz = tid0 / F2, iz = tid0 - pz * F2;                 // dz: column iz, rows j = pz + 6 m
+    const int iz = tid0 >> 2, pz = tid0 & 3;                       // dz: column iz (< F2), rows j = pz + 4 m
 #pragma unroll
-    for (int m = 0; m < 11; ++m) hwz[m] = (TRAIN && pz < 6 && pz + 6 * m < H) ? th[a.oFc1w + (int64_t)(pz + 6 * m) * F2 + iz] : 0.f;
-    const int pu = tid0 / E, eu = tid0 - pu * E;                   // u: column eu, rows f = pu + 5 m
+    for (int m = 0; m < 16; ++m) hwz[m] = (TRAIN && iz < F2) ? th[a.oFc1w + (int64_t)(pz + 4 * m) * F2 + iz] : 0.f;
+    const int eu = tid0 >> 2, pu = tid0 & 3;                       // u: column eu (< E), rows f = pu + 4 m
 #pragma unroll
-    for (int m = 0; m < 8; ++m) hwu[m] = (TRAIN && pu < 5) ? bf2f((__bf16)th[a.oWo + (int64_t)(pu + 5 * m) * E + eu]) : 0.f;
+    for (int m = 0; m < 10; ++m) hwu[m] = (TRAIN && eu < E) ? bf2f((__bf16)th[a.oWo + (int64_t)(pu + 4 * m) * E + eu]) : 0.f;
   }
   // first patch's tokens: 4 pieces of 16 bytes per thread, kept in registers and refilled one patch ahead
   uint4 tokr[4];
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       for (int i = tid; i < L::WPREP / 8; i += NT) dst[i] = src[i];
     };
     // projections of the wave's 16 tokens; writes Qs (both layouts), K (both layouts), V^T
-    auto project = [&](int lane, int g, int col) {
+    auto project = [&](int lane, int g, int col, int hb) {         // hb >= 0: backward of head hb, also forms a_j
       f32x4 q[2], k[2], v[2];
   #pragma unroll
       for (int n = 0; n < 2; ++n) q[n] = k[n] = v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       }
       // C layout: rows (tokens) m0 + 4g + r, column (feature) 16n + col
       const int rb = 4 * g;
+      float ap[4] = {0.f, 0.f, 0.f, 0.f};
   #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const unsigned q01 = pk2(q[n][0] * scale, q[n][1] * scale), q23 = pk2(q[n][2] * scale, q[n][3] * scale);
@@ -326,10 +329,22 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         pq[0 * QS] = lo_h(q01); pq[1 * QS] = hi_h(q01); pq[2 * QS] = lo_h(q23); pq[3 * QS] = hi_h(q23);
         pk[0 * KS] = lo_h(k01); pk[1 * KS] = hi_h(k01); pk[2 * KS] = lo_h(k23); pk[3 * KS] = hi_h(k23);
         const int o = (16 * n + col) * VS + m0 + rb;     // 4 consecutive tokens of one feature: one 8-byte store
+        const unsigned v01 = pk2(v[n][0], v[n][1]), v23 = pk2(v[n][2], v[n][3]);
         *reinterpret_cast<uint2*>(sQt + o) = make_uint2(q01, q23);
         *reinterpret_cast<uint2*>(sKt + o) = make_uint2(k01, k23);
-        *reinterpret_cast<uint2*>(sVt + o) = make_uint2(pk2(v[n][0], v[n][1]), pk2(v[n][2], v[n][3]));
+        *reinterpret_cast<uint2*>(sVt + o) = make_uint2(v01, v23);
+        if (hb >= 0) {                                   // a_j = sum_d bf16(V)[j][d] u_h[d]: this lane's features 16n + col
+          const float ud = sU[hb * DH + 16 * n + col];
+          ap[0] = fmaf(lo_f(v01), ud, ap[0]); ap[1] = fmaf(hi_f(v01), ud, ap[1]);
+          ap[2] = fmaf(lo_f(v23), ud, ap[2]); ap[3] = fmaf(hi_f(v23), ud, ap[3]);
+        }
       }
+      if (hb >= 0)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float aj = row16_sum(ap[r]);             // over the 16 lanes (features) of the token m0 + 4g + r
+          if (col == 0) sA[m0 + rb + r] = aj;
+        }
     };
     // P^T for the wave's queries: s[i][r] = P[t = tq][j = 16i + 4g + r]  (fp32, keys >= P2 masked)
     auto softmax_T = [&](f32x4 (&s)[8], int lane, int g, float& mx_out, float& inv_out) {
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       stage_weights(h, false, tidh);
       __syncthreads();
       ASTAMP();
-      project(lane, g, col);
+      project(lane, g, col, -1);
       __syncthreads();
       ASTAMP();
       f32x4 s[8];
@@ -499,54 +514,42 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       sDl[lane] = dl;
     }
     __syncthreads();
-    // head backward.  Every matrix-vector product is split over all 512 threads (partials through LDS, summed in a
-    // fixed order) with its weight loads issued back to back: a 64-term loop in 80 threads costs 64 L2 round trips.
-    {   // dh[j] = relu'(h[j]) sum_k W2[k][j] dl[k]                      thread <-> (j, part of 8)
-      const int j = tid & 63, part = tid >> 6;
+    // head backward.  Every matrix-vector product is split over the workgroup with its weights in registers; the parts
+    // of one output sit in adjacent lanes and are summed by DPP in a fixed order: one barrier per product.
+    {   // dh[j] = relu'(h[j]) sum_k W2[k][j] dl[k]                      thread <-> (j, part of 8): k = part + 8 i
+      const int j = tid >> 3, part = tid & 7;
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { const int k = part + 8 * i; acc = fmaf(hwd[i], k < K ? sDl[k] : 0.f, acc); }
-      sCw[part * T + j] = acc;
+      acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD); acc = AT_DPP(acc, 0x141, AT_ADD);
+      if (part == 0) sDh[j] = sHd[j] > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    if (tid < H) {
-      float dh = 0.f;
+    {   // dz[i] = sum_j W1[j][i] dh[j]                                   thread <-> (i, part of 4): j = part + 4 m
+      const int i = tid >> 2, part = tid & 3;
+      float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) dh += sCw[q * T + tid];
-      sDh[tid] = sHd[tid] > 0.f ? dh : 0.f;
-    }
-    __syncthreads();
-    {   // dz[i] = sum_j W1[j][i] dh[j]                                   thread <-> (i, part of 6): j = part + 6 m
-      const int part = tid / F2, i = tid - part * F2;
-      if (part < 6) {
-        float acc = 0.f;
-#pragma unroll
-        for (int m = 0; m < 11; ++m) { const int j = part + 6 * m; acc = fmaf(hwz[m], j < H ? sDh[j] : 0.f, acc); }
-        sCw[part * T + i] = acc;
+      for (int m = 0; m < 16; ++m) acc = fmaf(hwz[m], sDh[part + 4 * m], acc);
+      acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD);
+      if (part == 0 && i < F2) {
+        sDz[i] = acc;
+        a.ws_z[(size_t)b * F2 + i] = sZ[i];
+      }
+      if (tid >= NT - 64) {                          // (the last wave has no dz column)
+        const int j = tid - (NT - 64);
+        a.ws_h[(size_t)b * H + j] = sHd[j];
+        a.ws_dh[(size_t)b * H + j] = sDh[j];
+        a.ws_dl[(size_t)b * KMAX + j] = sDl[j];
       }
     }
     __syncthreads();
-    if (tid < F2) {
-      float dz = 0.f;
+    {   // u[e] = sum_f dza[f] bf16(Wo[f][e])                             thread <-> (e, part of 4): f = part + 4 m
+      const int e = tid >> 2, part = tid & 3;
+      float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) dz += sCw[q * T + tid];
-      sDz[tid] = dz;
-      a.ws_z[(size_t)b * F2 + tid] = sZ[tid];
-    } else if (tid >= 128 && tid < 128 + H) {
-      const int j = tid - 128;
-      a.ws_h[(size_t)b * H + j] = sHd[j];
-      a.ws_dh[(size_t)b * H + j] = sDh[j];
-      a.ws_dl[(size_t)b * KMAX + j] = sDl[j];
-    }
-    __syncthreads();
-    {   // u[e] = sum_f dza[f] bf16(Wo[f][e])                             thread <-> (e, part of 5): f = part + 5 m
-      const int part = tid / E, e = tid - part * E;
-      if (part < 5) {
-        float acc = 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc = fmaf(sDz[part + 5 * m], hwu[m], acc);
-        sCw[part * T + e] = acc;
-      }
+      for (int m = 0; m < 10; ++m) acc = fmaf(sDz[part + 4 * m], hwu[m], acc);
+      acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD);
+      if (part == 0 && e < E) sU[e] = acc;           // (read after the first barrier of pass 2)
     }
     // dWo[f][e] += dza[f] * obar[e]
 #pragma unroll
@@ -556,13 +559,6 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
         const float v = sDz[e / E] * sOb[e % E];
         slab_acc(slab + (size_t)3 * E * F + e, first, v);
       }
-    }
-    __syncthreads();
-    if (tid < E) {
-      float u = 0.f;
-#pragma unroll
-      for (int q = 0; q < 5; ++q) u += sCw[q * T + tid];
-      sU[tid] = u;
     }
 
     ASTAMP();                                        // 14: head forward + backward done
@@ -580,17 +576,12 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       stage_weights(h, true, tid);
       __syncthreads();
       ASTAMP();
-      project(lane, g, col);
+      project(lane, g, col, h);                      // (+ a_j = sum_d bf16(V)[j][d] u_h[d] of the own tokens)
       __syncthreads();
       ASTAMP();
-      // a_j = sum_d bf16(V)[j][d] u_h[d];  g_h[f] = sum_d u_h[d] bf16(Wv_h)[d][f]
-      if (tid < T) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < DH; ++d) s = fmaf(bf2f(__builtin_bit_cast(__bf16, sVt[d * VS + tid])), sU[h * DH + d], s);
-        sA[tid] = s;
-      } else if (tid < T + FO) {
-        const int f = tid - T;
+      // g_h[f] = sum_d u_h[d] bf16(Wv_h)[d][f]      (read after sync2)
+      if (tid >= NT - FO) {
+        const int f = tid - (NT - FO);
         float s = 0.f;
         for (int d = 0; d < DH; ++d) s = fmaf(sU[h * DH + d], bf2f(__builtin_bit_cast(__bf16, sWv[d * WS + f])), s);
         sG[f] = s;
@@ -599,7 +590,6 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       float mxq, invq;
       softmax_T(s, lane, g, mxq, invq);              // P[tq][j], j = 16i + 4g + r
       ASTAMP();
-      __syncthreads();                               // a_j visible
       {
         // abar_t = sum_j P[t][j] a_j      (c = bf16(P)^T w is formed with the own-KEY orientation below: no lane reductions)
         float ab = 0.f;
