@@ -183,6 +183,7 @@ struct V2 {
   static constexpr int NCOPY = TR ? NQ : 0;
   static constexpr int oDzix = oSlab + NCOPY * Sh::SLAB;  // training: per 16-byte slab piece, the dz indices of its 4 elements (8 bits each)
   static constexpr int NDZ = TR ? ((Sh::SLAB / 4 + 3) / 4) * 4 : 0;
+  static_assert(oDzix % 4 == 0, "the dz index table is staged in 16-byte pieces");
   // S > 1: the aux patch image [S P rows][RL = S P C2 floats] of EVERY patch lives in LDS (a lane needs S rows of it: too
   // many for registers).  The 16-byte chunks of a row are rotated by the PATCH row r = row / S, so that the 16 row-lanes
   // of a ds_read_b128 service group, whose rows are S RL floats = a multiple of 256 bytes apart, land on different banks;
@@ -371,6 +372,36 @@ __device__ __forceinline__ void dma_piece(const float* base, int soff, int voff,
 }
 __device__ __forceinline__ void gather_piece(const float* base, int soff, int voff, float* lds) { dma_piece<16>(base, soff, voff, lds); }
 
+// Channel (dz index) of every slab element, 8 bits each, one word per 16-byte slab piece: a compile-time table in the code
+// object's constant data, staged into LDS with the other patch-invariant tables (forming it in the kernel cost every
+// thread ~250 instructions of compare / branch chains IN FRONT of the first gather issue).
+template <class Sh>
+struct DzixTable {
+  static constexpr int N = ((Sh::SLAB / 4 + 3) / 4) * 4;
+  int v[N];
+  constexpr DzixTable() : v{} {
+    for (int t = 0; t < Sh::SLAB / 4; ++t) {
+      int w = 0;
+      for (int e = 0; e < 4; ++e) {
+        const int p = 4 * t + e;
+        int ix = 0;
+        if (p < Sh::oA1b) ix = p / Sh::Cg;
+        else if (p < Sh::oA2w) ix = p - Sh::oA1b;
+        else if (p < Sh::oA2b) ix = (p - Sh::oA2w) / 9;
+        else if (p < Sh::oB1w) ix = p - Sh::oA2b;
+        else if (p < Sh::oB1b) ix = Sh::F + (p - Sh::oB1w) / Sh::TB;
+        else if (p < Sh::oB2w) ix = Sh::F + p - Sh::oB1b;
+        else if (p < Sh::oB2b) ix = Sh::F + (p - Sh::oB2w) / 9;
+        else if (p < Sh::NCONV) ix = Sh::F + p - Sh::oB2b;
+        w |= ix << (8 * e);
+      }
+      v[t] = w;
+    }
+  }
+};
+template <class Sh>
+__device__ const DzixTable<Sh> g_dzix_table{};
+
 // INMODE: dmf_input.mode, compile time — with a run-time branch the waitcnt pass merges the two paths' states at the
 // join and waits vmcnt(0) there, i.e. for the whole window, before the aux phase.
 template <class Sh, int MODE, int INMODE, bool HF>
@@ -426,10 +457,15 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   //      wave q % NW.  Each wave waits for its own pieces (stage_wait) before the barrier in front of the first gather.
   {
     constexpr int NTHP = (Sh::SLAB / 4 + 63) / 64, NPLP = (P * V::RSP + 63) / 64;
+    constexpr int NDZP = (TR && !UNIT) ? (V::NDZ / 4 + 63) / 64 : 0;       // the dz index table (1-KiB pieces)
 #pragma unroll
-    for (int q = 0; q < NTHP + NPLP; ++q) {
+    for (int q = 0; q < NTHP + NPLP + NDZP; ++q) {
       if (q % V::NW != wave) continue;
-      if (q < NTHP) {
+      if (q >= NTHP + NPLP) {
+        const int c4 = (q - NTHP - NPLP) * 64 + lane;
+        dma_piece<16>(reinterpret_cast<const float*>(g_dzix_table<Sh>.v), 0, c4 < V::NDZ / 4 ? c4 * 16 : -1,
+                      smem + V::oDzix + (q - NTHP - NPLP) * 256);
+      } else if (q < NTHP) {
         const int c4 = q * 64 + lane;                      // 16-byte piece of theta
         dma_piece<16>(th, 0, c4 < Sh::SLAB / 4 ? (c4 < Sh::NCONV / 4 ? c4 : 0) * 16 : -1, sTh + q * 256);
       } else {
@@ -522,29 +558,8 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const KArgs a) {
   // sum of the quad copies of the UNIT gradients x dL/dz of each element's channel, in one coalesced pass (streaming stores:
   // next read by the reduce kernel).  A workgroup that walks several patches accumulates in its (L2-resident) global row.
   constexpr int NI = (Sh::SLAB / 4 + V::NT - 1) / V::NT;   // 16-byte slab pieces per thread
-  // channel (dz index) of each slab element, 8 bits each, one word per 16-byte piece: a table in LDS, written once here —
-  // kept in registers across the patch loop it is spilled to scratch (and scratch lines are written back at kernel end)
-  if constexpr (TR && !UNIT) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      int dzix = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int p = 4 * (tid + i * V::NT) + e;
-        int ix = 0;
-        if (p < Sh::oA1b) ix = p / Cg;
-        else if (p < Sh::oA2w) ix = p - Sh::oA1b;
-        else if (p < Sh::oA2b) ix = (p - Sh::oA2w) / 9;
-        else if (p < Sh::oB1w) ix = p - Sh::oA2b;
-        else if (p < Sh::oB1b) ix = F + (p - Sh::oB1w) / Sh::TB;
-        else if (p < Sh::oB2w) ix = F + p - Sh::oB1b;
-        else if (p < Sh::oB2b) ix = F + (p - Sh::oB2w) / 9;
-        else if (p < Sh::NCONV) ix = F + p - Sh::oB2b;
-        dzix |= ix << (8 * e);
-      }
-      if (tid + i * V::NT < Sh::SLAB / 4) reinterpret_cast<int*>(smem + V::oDzix)[tid + i * V::NT] = dzix;
-    }
-  }
+  // (channel (dz index) of each slab element: the staged DzixTable in LDS — kept in registers across the patch loop it is
+  // spilled to scratch, and scratch lines are written back at kernel end)
   auto scale_and_store = [&](int it, int b) {
     int tid_ = tid;
     OPAQUE(tid_);            // (addresses formed here, not carried — spilled — across the patch loop)
