@@ -303,6 +303,25 @@ class TrainEngine:
         self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
         _upload_graph(g)
 
+    def warm_graph(self):
+        """One replay of the captured graph that leaves no trace (weights, optimiser state, cursors and loss history are put
+        back): the first launch of a graph executable pays one-time costs of the launch machinery, which belong to a
+        warm-up.  bench.py calls it when the requested warm-up is shorter than one graph.  Single GPU only: under the
+        xGMI exchange a replay also advances the peers' inbox flags, which cannot be put back."""
+        if self.graph is None or self.world != 1 or self.host_cursor + self.graph_steps > self.plan_steps:
+            return False
+        state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
+        if self.scaler is not None:
+            state = state + (self.scaler.state,)
+        saved = [t.clone() for t in state]
+        self._fill_window(self.graph_steps)
+        self.graph.replay()
+        torch.cuda.synchronize()
+        for t, s_ in zip(state, saved):
+            t.copy_(s_)
+        torch.cuda.synchronize()
+        return True
+
     def _hparams(self):
         return (self.lr, self.b1, self.b2, self.eps, self.momentum, self.alpha) + (self.scaler.hparams() if self.scaler is not None else ())
 

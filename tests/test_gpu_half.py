@@ -371,3 +371,36 @@ def test_stage2_engine_with_the_references_other_optimizers(kind):
             assert (err > 1e-4 + 2e-4 * sd[k].abs()).float().mean() < 0.03 and err.max() < n * 2e-3, (k, err.max())
         else:
             assert_close(v, sd[k], 1e-4, 2e-4, 'stage-2 %s: param %s' % (kind, k))
+
+
+@pytest.mark.parametrize('half', [False, True])
+def test_warm_graph_leaves_no_trace(half):
+    """TrainEngine.warm_graph() replays the captured graph once and puts weights, optimiser state, cursors, loss history
+    (and the loss scaler's state) back: bench.py uses it when the requested warm-up is shorter than one graph.  A run with
+    it must be BIT-identical to a run without it."""
+    from dmf.engine import LossScaler, Scene, TrainEngine
+    from test_gpu_parity import nets
+    name = 'tiny1'
+    C, C2, P, S, K = SHAPES[name]
+    n, B, H, W, spg = 8, 16, 23, 19, 3
+    A, Bm = scene(name, H, W, 41)
+    g = torch.Generator().manual_seed(42)
+    xy = torch.stack([torch.randint(0, H, (n * B,), generator=g), torch.randint(0, W, (n * B,), generator=g)], 1).int()
+    t = torch.randint(0, K, (n * B,), generator=g)
+    out = []
+    for warm in (False, True):
+        cfg, ref, hip = nets(name)
+        sc = LossScaler('cuda:0', init_scale=2.0 ** 10, growth_interval=2) if half else None
+        eng = TrainEngine(hip, Scene(A.numpy(), Bm.numpy(), 'cuda:0', half=half), B, lr=1e-3, scaler=sc)
+        eng.load_plan(xy, t)
+        eng.run_plan(2, 0)                              # a warm-up shorter than one graph: eager steps
+        eng._capture(spg)
+        if warm:
+            assert eng.warm_graph()
+        eng.run_plan(n - 2, steps_per_graph=spg)        # two replays
+        out.append((eng.mean_losses().clone(), eng.theta.clone(), eng.m.clone(), eng.v.clone(),
+                    sc.get_scale() if half else None))
+    assert out[0][4] == out[1][4]
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert torch.equal(a, b)
+    assert out[0][0].numel() == n
