@@ -113,7 +113,7 @@ class TrainEngine:
         # device-side bookkeeping for graph replay
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.dev_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.plan_xy = self.plan_labels = self.loss_hist = None
+        self.plan_xy = self.plan_labels = self.plan_pack = self.loss_hist = None
         self.host_cursor = 0
         self.graph = None
         self.graph_steps = 0
@@ -222,10 +222,13 @@ class TrainEngine:
             raise lib.DmfError('label outside [0, %d)' % K)
         n = xy.shape[0] // self.B
         same = self.plan_xy is not None and self.plan_xy.shape == xy.shape
+        # the same stream once more, step by step [n][2B coordinates | B labels]: the window of a captured graph is refilled
+        # from it with ONE device copy per replay
+        pack = torch.cat([xy.view(n, 2 * self.B), lab.view(n, self.B)], 1).contiguous()
         if same:                                   # keep addresses stable for an already captured graph
-            self.plan_xy.copy_(xy); self.plan_labels.copy_(lab)
+            self.plan_xy.copy_(xy); self.plan_labels.copy_(lab); self.plan_pack.copy_(pack)
         else:
-            self.plan_xy, self.plan_labels = xy, lab
+            self.plan_xy, self.plan_labels, self.plan_pack = xy, lab, pack
             self.loss_hist = torch.zeros(n, device=dev)
             self.graph = None
         self.dev_cursor.zero_()
@@ -241,10 +244,8 @@ class TrainEngine:
         self.host_cursor += 1
 
     def _fill_window(self, n):
-        """Copy the next n steps of the plan into the fixed window the captured graph reads (two small async copies)."""
-        lo, hi = self.host_cursor * self.B, (self.host_cursor + n) * self.B
-        self.win_xy.copy_(self.plan_xy[lo:hi])
-        self.win_lab.copy_(self.plan_labels[lo:hi])
+        """Copy the next n steps of the plan into the fixed window the captured graph reads (one small async copy)."""
+        self.win.copy_(self.plan_pack[self.host_cursor:self.host_cursor + n])
 
     def run_plan(self, steps=None, steps_per_graph=0):
         """Run `steps` steps of the loaded plan (default: all).  steps_per_graph > 0 replays a captured hipGraph
@@ -287,18 +288,17 @@ class TrainEngine:
         # write-back / invalidate, and `kernarg -> cursor -> coordinates -> gather` is one dependent miss longer than
         # `kernarg -> coordinates -> gather`.  The window is refilled from the plan before every replay.
         dev = self.scene.device
-        self.win_xy = torch.empty(n * self.B, 2, dtype=torch.int32, device=dev)
-        self.win_lab = torch.empty(n * self.B, dtype=torch.int32, device=dev)
+        self.win = torch.empty(n, 3 * self.B, dtype=torch.int32, device=dev)      # per step: 2B coordinates, B labels
         if self.host_cursor + n <= self.plan_steps:
             self._fill_window(n)
         else:
-            self.win_xy.zero_(); self.win_lab.zero_()
+            self.win.zero_()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for k in range(n):
-                inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.win_xy[k * self.B:(k + 1) * self.B])
-                self._launch(inp, self.win_lab[k * self.B:(k + 1) * self.B], self.dev_step, self.dev_cursor, self.loss_hist)
+                inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.win[k, :2 * self.B].view(self.B, 2))
+                self._launch(inp, self.win[k, 2 * self.B:], self.dev_step, self.dev_cursor, self.loss_hist)
         self.step_count = count0
         self.graph, self.graph_steps, self.graph_hparams = g, n, self._hparams()
         _upload_graph(g)
