@@ -1,47 +1,87 @@
 """Build libdmf_hip.so (the C-ABI library declared in include/dmf.h) for gfx950, in-tree.
 
-    python dual-modal-fusion_amd/build.py [--force]
+    python dual-modal-fusion_amd/build.py [--force] [--stamps] [--shapes FILE]
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the tree.
+Every translation unit is compiled to its own object (in parallel, only when it or a header changed) and linked.
+
+Extra kernel instances: `--shapes FILE` (or the environment variable DMF_EXTRA_SHAPES) names a text file with one
+late-fusion shape per line, `C C2 P S F G` (bands, aux bands, patch, aux scale, gmf.width, spectral groups; H is 64) —
+each line adds one row to the v2 kernel's instance table (csrc/dmf_patch_v2.hip: DMF_V2_EXTRA_SHAPES).  A row the
+kernel's geometry cannot hold fails at compile time with the static_assert that names the rule.
 """
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, 'csrc', n) for n in ('dmf_patch_kernel.hip', 'dmf_patch_v2.hip', 'dmf_attention.hip', 'dmf_qua.hip', 'dmf_capi.hip')]
-HDR = [os.path.join(HERE, 'csrc', n) for n in ('dmf_shapes.h', 'dmf_kargs.h', 'dmf_lanes.h', 'dmf_xgmi.h')] + [ os.path.join(os.path.dirname(HERE), 'include', 'dmf.h')]
+NAMES = ('dmf_patch_kernel.hip', 'dmf_patch_v2.hip', 'dmf_attention.hip', 'dmf_qua.hip', 'dmf_capi.hip')
+SRC = [os.path.join(HERE, 'csrc', n) for n in NAMES]
+HDR = [os.path.join(HERE, 'csrc', n) for n in ('dmf_shapes.h', 'dmf_kargs.h', 'dmf_lanes.h', 'dmf_xgmi.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'dmf.h')]
 OUT = os.path.join(HERE, 'dmf', 'libdmf_hip.so')
+OBJ = os.path.join(HERE, 'build')
 # (-Wno-pass-failed: `#pragma unroll` on the run-time class loops of qua_loss_kernel<0> is a request, not a requirement)
-FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(p) <= t for p in SRC + HDR + [os.path.abspath(__file__)])
+def extra_shapes(path):
+    """`C C2 P S F G` lines -> the X-macro body appended to the v2 instance table."""
+    rows = []
+    if path:
+        for ln in open(path):
+            ln = ln.split('#')[0].strip()
+            if not ln:
+                continue
+            v = [int(t) for t in ln.replace(',', ' ').replace('/', ' ').split()]
+            if len(v) != 6:
+                raise SystemExit('%s: want "C C2 P S F G" per line, got %r' % (path, ln))
+            rows.append('X(%d, %d, %d, %d, %d, %d, 64)' % tuple(v))
+    return ' '.join(rows)
 
 
-def build(force=False, verbose=True, stamps=False):
-    """stamps=True builds the diagnostic variant libdmf_hip_stamps.so (-DDMF_STAMPS; tools/phase_profile.py)."""
-    if not stamps and not force and up_to_date():
-        return OUT
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=True, stamps=False, shapes=None):
+    """stamps=True builds the diagnostic variant libdmf_hip_stamps.so (-DDMF_STAMPS; tools/phase_profile_v2.py)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    shapes = shapes or os.environ.get('DMF_EXTRA_SHAPES')
+    extra = extra_shapes(shapes)
+    defs = (['-DDMF_STAMPS'] if stamps else []) + (['-DDMF_V2_EXTRA_SHAPES(X)=' + extra] if extra else [])
+    tag = hashlib.sha1(' '.join(FLAGS + defs).encode()).hexdigest()[:8]
     out = OUT.replace('.so', '_stamps.so') if stamps else OUT
-    cmd = [hipcc] + FLAGS + (['-DDMF_STAMPS'] if stamps else []) + SRC + ['-o', out]
-    if stamps:
+    os.makedirs(OBJ, exist_ok=True)
+    objs, jobs = [], []
+    for s in SRC:
+        o = os.path.join(OBJ, '%s.%s.o' % (os.path.basename(s), tag))
+        objs.append(o)
+        if force or _newer(o, [s] + HDR + [os.path.abspath(__file__)]):
+            jobs.append([hipcc] + FLAGS + defs + ['-c', s, '-o', o])
+    tagfile = out + '.tag'
+    relink = bool(jobs) or _newer(out, objs) or not os.path.exists(tagfile) or open(tagfile).read() != tag
+    if not relink:
+        return out
+
+    def run(cmd):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        return out
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return OUT
+    with ThreadPoolExecutor(max_workers=min(len(jobs), 5) or 1) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+    with open(tagfile, 'w') as f:
+        f.write(tag)
+    return out
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    shp = sys.argv[sys.argv.index('--shapes') + 1] if '--shapes' in sys.argv else None
+    build(force='--force' in sys.argv, shapes=shp)
     if '--stamps' in sys.argv:
-        build(stamps=True)
+        build(stamps=True, shapes=shp)

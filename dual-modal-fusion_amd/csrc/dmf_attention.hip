@@ -851,15 +851,11 @@ hipError_t attn_prep_launch(const float* theta, int64_t oWq, int64_t oWk, int64_
 
 template <class Sh, bool TRAIN>
 static hipError_t launch_attn_train(const AttnTrainArgs& a, int grid, hipStream_t st) {
-  static bool done = false;
+  static LdsAttrOnce once;
   constexpr size_t bytes = AttnTrainLds<Sh, 96, 3>::BYTES;
   static_assert(bytes <= 160 * 1024, "attention kernel LDS");
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_train_kernel<Sh, 96, 3, TRAIN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  hipError_t e = once.set(reinterpret_cast<const void*>(&attn_train_kernel<Sh, 96, 3, TRAIN>), (int)bytes);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((attn_train_kernel<Sh, 96, 3, TRAIN>), dim3(grid), dim3(512), bytes, st, a);
   return hipGetLastError();
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void adam_update(float* theta, float* m, float* v, in
 // Block layout: 16 consecutive parameters x 16 batch chunks (256 threads).  Every thread issues its chunk's loads
 // back to back (16 per pass), chunk partials are combined through LDS in a fixed tree, so the result does not
 // depend on scheduling.  The last block does the bookkeeping (per-step mean loss, epoch-plan cursor).
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
+__global__ __launch_bounds__(256) void grad_reduce_kernel_v1(const ReduceArgs a) {
   __shared__ float part[16][17];
   const int tid = threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {                 // bookkeeping block
@@ -175,6 +175,248 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs a) {
       a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
     }
   }
+}
+
+// ---- the reduce launch, second form (round 3).  Same sums in the same ORDER as the first form (rows / batch entries cut
+// into 16 chunks, each chunk summed front to back, the 16 partials combined by the fixed tree ((0+8)+(4+12)) + ((2+10)+(6+14))
+// + ... ), so every gradient bit is unchanged; what changed is who reads what:
+//   * conv (and attention) slabs: a block owns 64 consecutive parameters, a thread reads 16-byte pieces — a wave instruction
+//     covers four 256-byte row segments instead of four 64-byte ones, 27 blocks instead of 108 for the 200-band net;
+//   * fc1.weight / fc2.weight = dh^T z / dl^T h: one 16x16 output tile per block on the fp32 matrix cores
+//     (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered fmaf chain).  Wave w carries chunks w, w+4, w+8, w+12 in four
+//     accumulators; z / dh / h / dl are read ONCE per tile instead of once per parameter (the first form issued 41 K
+//     wave-level loads for them, this one 2.6 K);
+//   * the two bias vectors keep the first form's mapping (16 parameters x 16 chunks per block);
+//   * ADAM's bias corrections: b^step by repeated squaring in double on two lanes (beta1 / beta2 side by side) under the
+//     gradient loads, instead of two calls of the general pow() on one lane in front of the barrier.
+// Block order: fc tiles first (the longest chains), then slabs, biases, and the bookkeeping block last.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct ReducePlan { int nFc1, t1n, nFc2, nConv, nAttn, nBias; };   // blocks per kind (host and device agree through ReduceArgs)
+
+__device__ __forceinline__ double powi_double(double b, int n) {   // b^n, n >= 0, by squaring (relative error ~ 2 log2(n) ulp)
+  double r = 1.0;
+  while (n > 0) {
+    if (n & 1) r *= b;
+    b *= b;
+    n >>= 1;
+  }
+  return r;
+}
+
+// the fixed combine of 16 chunk partials (see above)
+__device__ __forceinline__ float tree16(float (&t)[16]) {
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int i = 0; i < w; ++i) t[i] += t[i + w];
+  return t[0];
+}
+
+// partial of one 16 x 16 tile of out[m][n] = sum_b U[b * su + m0 + m] * W[b * sw + n0 + n]: wave w's chunks, written to
+// vbuf[w] in output order (row * 16 + column).  Rows >= mlim / columns >= nlim read as zero.  Threads 0..255.
+__device__ __forceinline__ void fc_tile_partial(const float* __restrict__ U, int su, int m0, int mlim, const float* __restrict__ W,
+                                                int sw, int n0, int nlim, int B, float (*vbuf)[256]) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mn = lane & 15, kk = lane >> 4;
+  const bool mok = m0 + mn < mlim, nok = n0 + mn < nlim;
+  const float* up = U + m0 + mn;
+  const float* wp = W + n0 + mn;
+  const int per = (B + 15) / 16, nq = (per + 3) / 4;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int ci = 0; ci < 4; ++ci) acc[ci] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < nq; q0 += 4) {
+    float av[4][4], bv[4][4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      const int lo = (w + 4 * ci) * per, hi = min(B, lo + per);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int b = lo + 4 * (q0 + qq) + kk;
+        const bool in = q0 + qq < nq && b < hi;
+        av[ci][qq] = (in && mok) ? up[(size_t)b * su] : 0.f;
+        bv[ci][qq] = (in && nok) ? wp[(size_t)b * sw] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ci][qq], bv[ci][qq], acc[ci], 0, 0, 0);
+  }
+  const f32x4_t u0 = acc[0] + acc[2], u1 = acc[1] + acc[3], v = u0 + u1;   // chunks (w + w+8) + (w+4 + w+12)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vbuf[w][(4 * kk + r) * 16 + mn] = v[r];      // C layout: row 4 (lane >> 4) + r, column lane & 15
+}
+
+// Diagnostic build only (-DDMF_STAMPS, tools/reduce_phase_profile.py): clock stamps of every wave of the reduce launch in
+// scalar registers, dumped by lane 0 right before the wave ends.  [block][5 waves][8]: 0 entry, 1 role known (kernarg), 2 loads
+// issued, 3 partials written (loads landed), 4 behind the barrier, 5 stores issued, 6 end; 7 s_memrealtime at entry.
+#ifdef DMF_STAMPS
+__device__ unsigned long long* g_rstamps = nullptr;
+#define RSTAMP_DECL unsigned long long rst_[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
+#define RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(rst_[i])); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RSTAMP_RT(i) do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rst_[i])); } while (0)
+#define RSTAMP_DUMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); RSTAMP(6); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    if ((threadIdx.x & 63) == 0 && g_rstamps != nullptr) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) \
+      g_rstamps[((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 8 + i_] = rst_[i_]; } } while (0)
+#else
+#define RSTAMP_DECL do { } while (0)
+#define RSTAMP(i) do { } while (0)
+#define RSTAMP_RT(i) do { } while (0)
+#define RSTAMP_DUMP() do { } while (0)
+#endif
+
+// 320 threads: waves 0-3 reduce, wave 4 only forms ADAM's bias corrections (beside the other waves' gradient loads).
+__global__ __launch_bounds__(320) void grad_reduce_kernel(const ReduceArgs a, const ReducePlan pl) {
+  __shared__ float vbuf[4][256];        // tile partials of the four waves / [16 chunks][64] slab partials / [16][16] bias partials
+  __shared__ float bcs[2];
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  RSTAMP_DECL;
+  RSTAMP_RT(7);
+  RSTAMP(0);
+  if (blk == (int)gridDim.x - 1) {                   // bookkeeping block
+    const int cur = a.cursor_dev != nullptr ? *a.cursor_dev : 0;
+    if (a.loss != nullptr && a.loss_hist != nullptr) {
+      float s = 0.f;
+      float* red = &vbuf[0][0];
+      if (tid < 256) {
+        for (int b = tid; b < a.B; b += 256) s += a.loss[b];
+        red[tid] = s;
+      }
+      __syncthreads();
+      for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+      }
+      if (tid == 0) a.loss_hist[cur] = red[0] / (float)a.B;
+    }
+    if (tid == 0 && a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
+    return;
+  }
+  // ---- which parameter this thread finishes (p, own) — known before any gradient is read, so that the ADAM state is requested first
+  int kind, sub;                                     // 0 fc1.weight tile, 1 fc2.weight tile, 2 conv slab, 3 attention slab, 4 biases
+  if (blk < pl.nFc1) { kind = 0; sub = blk; }
+  else if ((blk -= pl.nFc1) < pl.nFc2) { kind = 1; sub = blk; }
+  else if ((blk -= pl.nFc2) < pl.nConv) { kind = 2; sub = blk; }
+  else if ((blk -= pl.nConv) < pl.nAttn) { kind = 3; sub = blk; }
+  else { kind = 4; sub = blk - pl.nAttn; }
+  int64_t p = 0;
+  bool own = false;
+  int m0 = 0, n0 = 0;
+  if (kind == 0) {
+    m0 = 16 * (sub / pl.t1n); n0 = 16 * (sub % pl.t1n);
+    const int j = m0 + (tid >> 4), i = n0 + (tid & 15);
+    own = j < a.H && i < a.F2;
+    p = a.oFc1w + (int64_t)j * a.F2 + i;
+  } else if (kind == 1) {
+    const int t2n = a.H / 16;
+    m0 = 16 * (sub / t2n); n0 = 16 * (sub % t2n);
+    const int k = m0 + (tid >> 4), j = n0 + (tid & 15);
+    own = k < a.K && j < a.H;
+    p = a.oFc2w + (int64_t)k * a.H + j;
+  } else if (kind == 2) {
+    p = (int64_t)64 * sub + tid;
+    own = tid < 64 && p < a.NCONV;
+  } else if (kind == 3) {
+    p = a.oAttn + (int64_t)64 * sub + tid;
+    own = tid < 64 && 64 * sub + tid < a.ASLAB;
+  } else {
+    const int q = 16 * sub + tid;
+    own = tid < 16 && q < a.H + a.K;
+    p = q < a.H ? a.oFc1b + q : a.oFc2b + (q - a.H);
+  }
+  own = own && tid < 256;
+  RSTAMP(1);
+  float th0 = 0.f, m_0 = 0.f, v_0 = 0.f;
+  if (own && a.theta != nullptr) { th0 = a.theta[p]; m_0 = a.m[p]; v_0 = a.v[p]; }
+  float* part = &vbuf[0][0];
+  if (tid >= 256) {
+    // bias corrections (lanes 0 / 1 of wave 4: beta1 / beta2 side by side), b^step by repeated squaring in double
+    if (a.theta != nullptr && tid < 258) {
+      float bc = tid == 256 ? a.bc1 : a.bc2_sqrt;
+      if (a.step_dev != nullptr) {
+        const double pw = powi_double((double)(tid == 256 ? a.b1 : a.b2), *a.step_dev);
+        bc = tid == 256 ? (float)(1.0 - pw) : (float)sqrt(1.0 - pw);
+      }
+      bcs[tid - 256] = bc;
+    }
+  } else if (kind == 0) {
+    fc_tile_partial(a.dh, a.H, m0, a.H, a.z, a.F2, n0, a.F2, a.B, vbuf);
+  } else if (kind == 1) {
+    fc_tile_partial(a.dl, KMAX, m0, a.K, a.h, a.H, n0, a.H, a.B, vbuf);
+  } else if (kind == 2 || kind == 3) {
+    const bool att = kind == 3;
+    const int pitch = att ? a.ASLAB : a.SLAB, nb = att ? a.nablk : a.nblk;
+    const int c4 = tid & 15, ch = tid >> 4;
+    const bool in_row = 64 * sub + 4 * c4 < pitch;
+    const float* sl = (att ? a.aslab : a.slab) + 64 * sub + 4 * c4;
+    const int per = (nb + 15) / 16;
+    const int lo = ch * per, hi = min(nb, lo + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = lo; b0 < hi; b0 += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        v[i] = (in_row && b0 + i < hi) ? *reinterpret_cast<const float4*>(sl + (size_t)(b0 + i) * pitch) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    *reinterpret_cast<float4*>(part + ch * 64 + 4 * c4) = acc;          // [16 chunks][64]
+  } else {
+    const int jj = tid & 15, ch = tid >> 4, q = 16 * sub + jj;
+    const int per = (a.B + 15) / 16;
+    const int lo = ch * per, hi = min(a.B, lo + per);
+    float acc = 0.f;
+    if (q < a.H + a.K) {
+      const float* u = q < a.H ? a.dh + q : a.dl + (q - a.H);
+      const int su = q < a.H ? a.H : KMAX;
+      for (int b0 = lo; b0 < hi; b0 += 16) {
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (b0 + i < hi) ? u[(size_t)(b0 + i) * su] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += x[i];
+      }
+    }
+    part[ch * 16 + jj] = acc;                                           // [16 chunks][16]
+  }
+  RSTAMP(3);
+  __syncthreads();
+  RSTAMP(4);
+  float g = 0.f;
+  if (tid < 256) {
+    if (kind < 2) {
+      g = (vbuf[0][tid] + vbuf[2][tid]) + (vbuf[1][tid] + vbuf[3][tid]);
+    } else if (tid < 64) {
+      const int stride = kind == 4 ? 16 : 64;
+      if (kind != 4 || tid < 16) {
+        float t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = part[i * stride + tid];
+        g = tree16(t);
+      }
+    }
+  }
+  if (a.x.world > 1)                                 // block-uniform: every thread takes part in the barriers
+    g = xgmi_exchange(a.x, 0, *a.step_dev + a.seq_bias, blockIdx.x, p, own, g) * a.grad_scale;
+  if (own) {
+    if (a.scaler != nullptr) {                       // unscale_ + the found_inf check of GradScaler, in the reduce
+      g *= 1.f / a.scaler[0];
+      if (!isfinite(g)) a.scaler[2] = 1.f;           // (every writer stores the same value)
+    }
+    if (a.grad != nullptr) a.grad[p] = g;
+    if (a.theta != nullptr) {
+      const float mn = m_0 + (g - m_0) * (1.f - a.b1);
+      const float vn = v_0 * a.b2 + (1.f - a.b2) * g * g;
+      a.m[p] = mn;
+      a.v[p] = vn;
+      a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
+    }
+  }
+  RSTAMP(5);
+  RSTAMP_DUMP();
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* theta, const float* grad, float* m, float* v, int64_t n,
@@ -320,9 +562,10 @@ int32_t dmf_shape_supported(const dmf_shape* s) {
   return 1;
 }
 
-int32_t dmf_patch_variant(const dmf_shape* s, int32_t mode) {
-  if (s == nullptr || !patch_shape_supported(*s)) return 0;
-  return (!force_v1() && !s->attention && patch_v2_supported(*s, mode)) ? 2 : 1;
+int32_t dmf_patch_variant(const dmf_shape* s, int32_t mode) {   // the same decision as run_patch / dmf_shape_supported
+  if (s == nullptr) return 0;
+  if (!force_v1() && !s->attention && patch_v2_supported(*s, mode)) return 2;
+  return patch_shape_supported(*s) ? 1 : 0;
 }
 
 int32_t dmf_param_layout(const dmf_shape* s, int64_t offsets[17]) {
@@ -637,8 +880,23 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
     if (fill_xgmi(comm, a.x)) return 1;
     a.seq_bias = comm->seq_bias;
   }
-  const int grid = (int)((L.n_params + 15) / 16) + 1;   // + the bookkeeping block
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const char* e_v1 = getenv("DMF_REDUCE_V1");             // (temporary A/B switch: the first form of the kernel)
+  if (e_v1 != nullptr && e_v1[0] == '1') {
+    const int grid = (int)((L.n_params + 15) / 16) + 1;   // + the bookkeeping block
+    hipLaunchKernelGGL(grad_reduce_kernel_v1, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check(hipGetLastError(), "grad_reduce launch");
+  }
+  if (L.H % 16 != 0) return fail("%s", "grad_reduce: hidden width must be a multiple of 16");
+  ReducePlan pl{};
+  pl.t1n = (L.F2 + 15) / 16;
+  pl.nFc1 = (L.H / 16) * pl.t1n;
+  pl.nFc2 = ((L.K + 15) / 16) * (L.H / 16);
+  pl.nConv = (L.NCONV + 63) / 64;
+  pl.nAttn = L.attention ? (a.ASLAB + 63) / 64 : 0;
+  pl.nBias = (L.H + L.K + 15) / 16;
+  const int grid = pl.nFc1 + pl.nFc2 + pl.nConv + pl.nAttn + pl.nBias + 1;   // + the bookkeeping block
+  if (comm != nullptr && grid > a.x.nblk) return fail("%s", "xgmi communicator has fewer block flags than the reduce grid");
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(320), 0, static_cast<hipStream_t>(stream), a, pl);
   return check(hipGetLastError(), "grad_reduce launch");
 }
 
@@ -826,6 +1084,7 @@ int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, doubl
 }
 
 #ifdef DMF_STAMPS
+int32_t dmf_debug_set_reduce_stamps(void* p) { return check(hipMemcpyToSymbol(HIP_SYMBOL(dmf::g_rstamps), &p, sizeof(p)), "set_reduce_stamps"); }
 int32_t dmf_debug_set_attn_stamps(void* p) { return check(dmf::set_attn_stamps(static_cast<unsigned long long*>(p)), "set_attn_stamps"); }
 int32_t dmf_debug_set_stamps(void* p) { return check(dmf::set_stamps(static_cast<unsigned long long*>(p)), "set_stamps"); }
 int32_t dmf_debug_set_v2_stamps(void* p) { return check(dmf::set_v2_stamps(static_cast<unsigned long long*>(p)), "set_v2_stamps"); }

@@ -4,10 +4,32 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/dmf.h"
 #include "dmf_shapes.h"
 
 namespace dmf {
+
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (kernel, device) pair and is not capturable: every launch
+// site keeps ONE of these per kernel instance (a function-local static) and calls set() before the launch — once per device,
+// under a lock (two host threads may reach a first launch together).
+struct LdsAttrOnce {
+  std::mutex mu;
+  bool done[64] = {};
+  hipError_t set(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[dev] = (e == hipSuccess);
+    return e;
+  }
+};
 
 enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE = 4, MODE_UNIT = 5 };
 // TOKENS: conv stages only, for the attention kernel.  DENSE: conv backward from dense dL/dYa, dL/dYb maps [B][F][P2]

@@ -941,13 +941,8 @@ static hipError_t launch_patch(int mode, const KArgs& a, hipStream_t st) {
   using L = Lds<Sh>;
   const int grid = a.in.B < MAX_BLOCKS ? a.in.B : MAX_BLOCKS;
   hipError_t e = hipSuccess;
-  static bool attr_done[5] = {false, false, false, false, false};
-  auto set_attr = [&](const void* fn, int m) {
-    if (!attr_done[m]) {
-      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
-      attr_done[m] = (e == hipSuccess);
-    }
-  };
+  static LdsAttrOnce once[5];
+  auto set_attr = [&](const void* fn, int m) { e = once[m].set(fn, L::BYTES); };
   if (grid <= 0) return hipSuccess;
   switch (mode) {
     case MODE_FWD:

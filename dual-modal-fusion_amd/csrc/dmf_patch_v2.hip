@@ -1355,13 +1355,9 @@ __global__ __launch_bounds__(256) void unit_backward_kernel(const UnitBwdArgs a)
 // ---------------------------------------------------------------------------------------- launch
 template <class Sh, int MODE, int INMODE, bool HF>
 static hipError_t launch_v2_inst(const KArgs& a, int grid, int bytes, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_v2_kernel<Sh, MODE, INMODE, HF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  hipError_t e = once.set(reinterpret_cast<const void*>(&patch_v2_kernel<Sh, MODE, INMODE, HF>), 160 * 1024);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((patch_v2_kernel<Sh, MODE, INMODE, HF>), dim3(grid), dim3(V2<Sh>::NT), bytes, st, a);
   return hipGetLastError();
 }
@@ -1389,11 +1385,14 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
 
 // Compiled instances: ONE table.  X(C, C2, P, S, F, G, H) — every row gets forward / train / backward-from-dlogits /
 // unit-gradient kernels for both input modes, the unit backward kernel, and its line in the supported-shape listing.
-// A row must satisfy V2<>::OK (S = 1, whole 16-byte band chunks per group, <= 12 waves) and fit 160 KiB of LDS at the
+// A row must satisfy V2<>::OK (S = 1 or 4, whole 16-byte band chunks per group, <= 12 waves) and fit 160 KiB of LDS at the
 // run-time K (v2_fits): 13x13 patches of a 200-band scene do not (the window alone is 135 KB) — no instance can exist
 // for them on this design; 224 bands at gmf.width 40 (G | gcd(224, 40) = 8: 5 channels per group) would need 175.6 KB here
 // (window 109.6 + three slab-row copies 25.7 + transposed fc1 20.5 + staged theta 8.6 + ...), and the generic kernel owns a
 // group's channels in 4-channel blocks (M % 4 == 0).
+#ifndef DMF_V2_EXTRA_SHAPES
+#define DMF_V2_EXTRA_SHAPES(X)
+#endif
 #define DMF_V2_SHAPES(X)                                                                                      \
   X(200, 1, 11, 1, 40, 10, 64) /* BASELINE configs 1-2 */                                                     \
   X(200, 1, 9, 1, 40, 10, 64)                                                                                 \
@@ -1404,7 +1403,8 @@ static hipError_t launch_v2(int mode, const KArgs& a, hipStream_t st) {
   X(4, 1, 16, 1, 40, 1, 64)    /* stage 2 of the two-stage path: one 4-band stream + its band mean */          \
   X(4, 1, 5, 1, 40, 1, 64)     /* the same on the small test scene */                                         \
   X(4, 1, 16, 4, 40, 1, 64)    /* the reference's own data: 4-band MS + PAN at 4x (config.yml:27,77-110) */         \
-  X(8, 1, 5, 4, 40, 2, 64)     /* small test scene, aux at 4x */
+  X(8, 1, 5, 4, 40, 2, 64)     /* small test scene, aux at 4x */                                              \
+  DMF_V2_EXTRA_SHAPES(X)       /* rows added at build time: build.py --shapes FILE */
 // ... the rows of the attention network (gmf.attention; attention block: F = 40, E = 96), which also get the two launches of
 // its train step / forward that are conv work: MODE_TOKENS and MODE_DENSE
 #define DMF_V2_ATTN_SHAPES(X)                                                                                 \

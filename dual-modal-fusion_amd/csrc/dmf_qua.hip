@@ -431,15 +431,10 @@ hipError_t launch_qua_loss(const QuaArgs& a, hipStream_t st) {
   ts = ts > 256 ? 256 : (ts < 1 ? 1 : ts);
   if (ts > a.bs) ts = a.bs;
   const size_t bytes = (size_t)(QT + 10 * ts * a.K) * sizeof(float);
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qua_loss_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qua_loss_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  static LdsAttrOnce once16, once0;
+  hipError_t e = once16.set(reinterpret_cast<const void*>(&qua_loss_kernel<16>), 160 * 1024);
+  if (e == hipSuccess) e = once0.set(reinterpret_cast<const void*>(&qua_loss_kernel<0>), 160 * 1024);
+  if (e != hipSuccess) return e;
   if (a.K <= 16) hipLaunchKernelGGL(qua_loss_kernel<16>, dim3(1), dim3(QT), bytes, st, a, ts);
   else hipLaunchKernelGGL(qua_loss_kernel<0>, dim3(1), dim3(QT), bytes, st, a, ts);
   return hipGetLastError();

@@ -21,16 +21,43 @@ import torch
 from . import lib
 
 
+_hip_graph_upload = None
+
+
+def _hip_runtime_of_torch():
+    """The libamdhip64 this process already has mapped (torch's own), found in /proc/self/maps — dlopen by bare name could
+    bind a second copy of the runtime, whose graph handles mean nothing to the first."""
+    import ctypes
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if line.count('/') else ''
+                if 'libamdhip64.so' in path:
+                    return ctypes.CDLL(path)
+    except OSError:
+        pass
+    return None
+
+
 def _upload_graph(g):
     """hipGraphUpload of a freshly captured graph: its first replay otherwise pays the upload (~20 us, measured with
-    tools/graph_first.py) inside whatever the caller is timing.  Best effort: any failure leaves the lazy upload in place."""
-    try:
-        import ctypes
-        hip = ctypes.CDLL('libamdhip64.so')
-        hip.hipGraphUpload.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        hip.hipGraphUpload(ctypes.c_void_p(g.raw_cuda_graph_exec()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    except Exception:
-        pass
+    tools/graph_first.py) inside whatever the caller is timing.  Returns True when the upload happened; a missing symbol or a
+    non-zero return code leaves the lazy upload in place (correct either way, only the first replay is slower)."""
+    global _hip_graph_upload
+    import ctypes
+    if _hip_graph_upload is None:
+        rt = _hip_runtime_of_torch()
+        fn = getattr(rt, 'hipGraphUpload', None) if rt is not None else None
+        if fn is None:
+            _hip_graph_upload = False
+        else:
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            fn.restype = ctypes.c_int
+            _hip_graph_upload = fn
+    if not _hip_graph_upload:
+        return False
+    rc = _hip_graph_upload(ctypes.c_void_p(g.raw_cuda_graph_exec()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return rc == 0
 
 
 class Scene:
@@ -239,6 +266,8 @@ class TrainEngine:
         return n
 
     def _plan_step(self):
+        if self.host_cursor >= self.plan_steps:          # the kernel reads plan[cursor] unchecked: never step past the plan
+            raise lib.DmfError('the loaded plan has %d steps, all of them are done' % self.plan_steps)
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=self.B, cursor=self.dev_cursor)
         self._launch(inp, self.plan_labels, self.dev_step, self.dev_cursor, self.loss_hist)
         self.host_cursor += 1
@@ -250,7 +279,10 @@ class TrainEngine:
     def run_plan(self, steps=None, steps_per_graph=0):
         """Run `steps` steps of the loaded plan (default: all).  steps_per_graph > 0 replays a captured hipGraph
         (single GPU, or data parallel over the xgmi communicator); 0 launches eagerly.  No host synchronisation."""
-        steps = self.plan_steps if steps is None else steps
+        steps = self.plan_steps - self.host_cursor if steps is None else steps
+        if self.plan_xy is None or steps < 0 or self.host_cursor + steps > self.plan_steps:
+            raise lib.DmfError('run_plan(%d): the loaded plan has %d steps, %d of them done' % (
+                steps, getattr(self, 'plan_steps', 0), self.host_cursor))
         done = 0
         if steps_per_graph > 0 and (self.world == 1 or self.comm is not None):
             # lr, betas and eps are launch arguments baked into the captured graph (reference: `scheduler.step()` changes
@@ -632,6 +664,8 @@ class QuaTrainEngine:
         return n
 
     def _plan_step(self):
+        if self.host_cursor >= self.plan_steps:          # the kernel reads plan[cursor] unchecked: never step past the plan
+            raise lib.DmfError('the loaded plan has %d steps, all of them are done' % self.plan_steps)
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy, B=4 * self.bs, cursor=self.dev_cursor)
         self._step(inp, self.bs, self.plan_labels, self.dev_cursor, self.loss_hist, self.dev_step)
         self.host_cursor += 1
@@ -663,7 +697,10 @@ class QuaTrainEngine:
         _upload_graph(g)
 
     def run_plan(self, steps=None, steps_per_graph=0):
-        steps = self.plan_steps if steps is None else steps
+        steps = self.plan_steps - self.host_cursor if steps is None else steps
+        if self.plan_xy is None or steps < 0 or self.host_cursor + steps > self.plan_steps:
+            raise lib.DmfError('run_plan(%d): the loaded plan has %d steps, %d of them done' % (
+                steps, getattr(self, 'plan_steps', 0), self.host_cursor))
         done = 0
         if steps_per_graph > 0 and self.unit and self.world == 1:
             if self.graph is None or self.graph_steps != steps_per_graph or self.graph_hparams != self._hparams():

@@ -28,7 +28,7 @@ from PIL import Image
 from tqdm import tqdm
 
 from solver.basesolver import BaseSolver
-from utils.utils import epoch_hparams, make_loss, optim_hparams, make_optimizer, make_scheduler, save_checkpoint
+from utils.utils import epoch_hparams, export_optimizer, make_loss, optim_hparams, make_optimizer, make_scheduler, save_checkpoint
 
 
 class Solver(BaseSolver):
@@ -63,16 +63,16 @@ class Solver(BaseSolver):
         return torch.stack([x, y], 1).to(torch.int32), label.to(torch.int32)
 
     def _export_optimizer(self):
-        """torch-Adam-format optimiser state from the engine's flat moments (checkpoint interchange)."""
+        """The configured optimiser (ADAM, SGD or RMSprop) with its own state keys, from the engine's flat state vectors
+        (checkpoint interchange with the reference's save_checkpoint / load_checkpoint, utils/utils.py:82-102)."""
         eng = self.engine
-        opt = torch.optim.Adam(self.cur_model.parameters(), lr=eng.lr)
-        off = self.cur_model._offsets
-        for i, p in enumerate(self.cur_model._named()):
-            n = p.numel()
-            opt.state[p] = {'step': torch.tensor(float(eng.step_count)),
-                            'exp_avg': eng.m[off[i]:off[i] + n].view(p.shape).clone(),
-                            'exp_avg_sq': eng.v[off[i]:off[i] + n].view(p.shape).clone()}
-        return opt
+        group = {'lr': eng.lr}
+        if eng.optim == 'ADAM':
+            group['betas'] = (eng.b1, eng.b2)
+        elif eng.optim == 'SGD':
+            group['momentum'] = eng.momentum
+        return export_optimizer(self.cfg, self.cur_model.parameters(), self.cur_model._named(), self.cur_model._offsets, eng.m, eng.v,
+                                eng.step_count, group)
 
     # ------------------------------------------------------------------ train
     def train(self):

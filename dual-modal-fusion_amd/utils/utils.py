@@ -150,6 +150,39 @@ def epoch_lr(cfg, epoch):
     return float(epoch_hparams(cfg, epoch)['lr'])
 
 
+def export_optimizer(cfg, params, flat_params, offsets, m, v, step_count, group=None):
+    """The torch optimiser `make_optimizer(cfg, params)` would be after `step_count` steps, filled from the resident-scene
+    engine's flat state vectors — so that `<time>_curweights.pth` holds what the reference's `save_checkpoint(model,
+    optimizer)` stores (utils/utils.py:82-88) and `load_checkpoint` (:91-102) can feed it to `make_optimizer(cfg)` again.
+    Per optimiser kind (torch's own state keys):
+      ADAM     m -> exp_avg, v -> exp_avg_sq, step
+      SGD      m -> momentum_buffer (only when momentum != 0 and a step has been taken, as torch creates it)
+      RMSprop  m -> square_avg, step
+    params: `model.parameters()` — the order the reference hands to make_optimizer, which is the order a state_dict numbers
+    them in; flat_params / offsets: the same nn.Parameters in flat-vector order with their start in m / v; group:
+    hyper-parameters in force (lr after the scheduler, OneCycleLR's betas / momentum) written into the parameter group."""
+    opt = make_optimizer(cfg, list(params))
+    kind = cfg['schedule']['optimizer']
+    if group:
+        for k, val in group.items():
+            if k in opt.param_groups[0] and k != 'params':
+                opt.param_groups[0][k] = val
+    for i, p in enumerate(flat_params):
+        n = p.numel()
+        seg_m = m[offsets[i]:offsets[i] + n].view(p.shape).clone()
+        if step_count <= 0:                       # torch creates an optimiser's state on its first step
+            continue
+        if kind == 'ADAM':
+            opt.state[p] = {'step': torch.tensor(float(step_count)), 'exp_avg': seg_m,
+                            'exp_avg_sq': v[offsets[i]:offsets[i] + n].view(p.shape).clone()}
+        elif kind == 'SGD':
+            if opt.param_groups[0]['momentum'] != 0:
+                opt.state[p] = {'momentum_buffer': seg_m}
+        elif kind == 'RMSprop':
+            opt.state[p] = {'step': torch.tensor(float(step_count)), 'square_avg': seg_m}
+    return opt
+
+
 # ---------------------------------------------------------------------------------------------- checkpoints
 def _bundle(model, optimizer, **extra):
     d = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict()}

@@ -416,3 +416,58 @@ def test_fast_path_hyperparameters_follow_every_scheduler_kind():
     import pytest
     with pytest.raises(ValueError):
         u.optim_hparams({'schedule': dict(sched, optimizer='LBFGS')})
+
+
+@pytest.mark.parametrize('kind', ['ADAM', 'SGD', 'RMSprop'])
+def test_fast_path_checkpoint_holds_the_configured_optimizer(kind, tmp_path):
+    """`<time>_curweights.pth` of the fast path must hold what the reference's save_checkpoint(model, optimizer) stores
+    (utils/utils.py:82-88) for the CONFIGURED optimiser (make_optimizer, :8-19): torch's own state keys, numbered in
+    `model.parameters()` order, loadable by load_checkpoint (:91-102) into make_optimizer(cfg).  The engine's flat state
+    vectors (m = exp_avg / momentum_buffer / square_avg, v = exp_avg_sq) are emulated from a torch optimiser that took
+    the same steps; the export must reproduce that optimiser's state_dict and continue identically after a reload."""
+    from model.gmfnet import Net
+    from utils.utils import export_optimizer, load_checkpoint, make_optimizer, save_checkpoint
+    cfg = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [9, 9, 8]}}, 'scale': 1, 'aux_bands': 1,
+           'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0},
+           'schedule': {'optimizer': kind, 'lr': 1e-2, 'momentum': 0.9, 'alpha': 0.95}}
+    torch.manual_seed(0)
+    net = Net(cfg)
+    opt = make_optimizer(cfg, net.parameters())
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        for p in net.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+    # the engine's view: flat vectors in the library's parameter order
+    flat, off = net._named(), net._offsets
+    n = off[16]
+    m, v = torch.zeros(n), torch.zeros(n)
+    key_m = {'ADAM': 'exp_avg', 'SGD': 'momentum_buffer', 'RMSprop': 'square_avg'}[kind]
+    for i, p in enumerate(flat):
+        m[off[i]:off[i] + p.numel()] = opt.state[p][key_m].reshape(-1)
+        if kind == 'ADAM':
+            v[off[i]:off[i] + p.numel()] = opt.state[p]['exp_avg_sq'].reshape(-1)
+    exp = export_optimizer(cfg, net.parameters(), flat, off, m, v, 3, {'lr': 5e-3})
+    want, got = opt.state_dict(), exp.state_dict()
+    assert type(exp) is type(opt)
+    assert got['param_groups'][0]['params'] == want['param_groups'][0]['params']
+    assert got['param_groups'][0]['lr'] == 5e-3
+    assert set(got['state']) == set(want['state'])
+    for idx in want['state']:
+        assert set(got['state'][idx]) == set(want['state'][idx]), (kind, idx)
+        for k, val in want['state'][idx].items():
+            assert torch.equal(torch.as_tensor(got['state'][idx][k]).float(), torch.as_tensor(val).float()), (kind, idx, k)
+    # reference round trip: save_checkpoint -> load_checkpoint into a freshly made optimiser -> one more identical step
+    path = str(tmp_path / 'cur.pth')
+    save_checkpoint(net, exp, path)
+    net2 = Net(cfg)
+    opt2 = make_optimizer(cfg, net2.parameters())
+    load_checkpoint(path, net2, opt2, 1e-2, 'cpu')
+    for p, q in zip(net.parameters(), net2.parameters()):
+        gr = torch.randn(p.shape, generator=g)
+        p.grad, q.grad = gr, gr.clone()
+    opt.step(); opt2.step()
+    for p, q in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(p.data, q.data)
+    # before any step the export carries no state (torch creates it on the first step)
+    assert export_optimizer(cfg, net.parameters(), flat, off, m, v, 0).state_dict()['state'] == {}
