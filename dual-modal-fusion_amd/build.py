@@ -24,6 +24,9 @@ OUT = os.path.join(HERE, 'dmf', 'libdmf_hip.so')
 OBJ = os.path.join(HERE, 'build')
 # (-Wno-pass-failed: `#pragma unroll` on the run-time class loops of qua_loss_kernel<0> is a request, not a requirement)
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
+# per-file extras: the reduce launch and the v2 patch kernel take their hot scalars as leading kernel arguments and have
+# them preloaded into SGPRs at wave launch (see grad_reduce_kernel, patch_v2_kernel)
+EXTRA = {'dmf_capi.hip': ['-mllvm', '-amdgpu-kernarg-preload-count=14'], 'dmf_patch_v2.hip': ['-mllvm', '-amdgpu-kernarg-preload-count=14']}
 
 
 def extra_shapes(path):
@@ -48,21 +51,24 @@ def _newer(target, deps):
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force=False, verbose=True, stamps=False, shapes=None):
-    """stamps=True builds the diagnostic variant libdmf_hip_stamps.so (-DDMF_STAMPS; tools/phase_profile_v2.py)."""
+def build(force=False, verbose=True, stamps=False, shapes=None, defines=(), suffix=None):
+    """stamps=True builds the diagnostic variant libdmf_hip_stamps.so (-DDMF_STAMPS; tools/phase_profile_v2.py).
+    defines / suffix: an experimental variant libdmf_hip_<suffix>.so with extra -D switches (A/B runs, tools/ab.sh)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     shapes = shapes or os.environ.get('DMF_EXTRA_SHAPES')
     extra = extra_shapes(shapes)
-    defs = (['-DDMF_STAMPS'] if stamps else []) + (['-DDMF_V2_EXTRA_SHAPES(X)=' + extra] if extra else [])
-    tag = hashlib.sha1(' '.join(FLAGS + defs).encode()).hexdigest()[:8]
+    defs = (['-DDMF_STAMPS'] if stamps else []) + (['-DDMF_V2_EXTRA_SHAPES(X)=' + extra] if extra else []) + ['-D' + d for d in defines]
+    tag = hashlib.sha1(' '.join(FLAGS + defs + [repr(sorted(EXTRA.items()))]).encode()).hexdigest()[:8]
     out = OUT.replace('.so', '_stamps.so') if stamps else OUT
+    if suffix:
+        out = OUT.replace('.so', '_%s.so' % suffix)
     os.makedirs(OBJ, exist_ok=True)
     objs, jobs = [], []
     for s in SRC:
         o = os.path.join(OBJ, '%s.%s.o' % (os.path.basename(s), tag))
         objs.append(o)
         if force or _newer(o, [s] + HDR + [os.path.abspath(__file__)]):
-            jobs.append([hipcc] + FLAGS + defs + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + defs + ['-c', s, '-o', o])
     tagfile = out + '.tag'
     relink = bool(jobs) or _newer(out, objs) or not os.path.exists(tagfile) or open(tagfile).read() != tag
     if not relink:
@@ -82,6 +88,10 @@ def build(force=False, verbose=True, stamps=False, shapes=None):
 
 if __name__ == '__main__':
     shp = sys.argv[sys.argv.index('--shapes') + 1] if '--shapes' in sys.argv else None
+    if '--define' in sys.argv:                   # python build.py --define A=1 [--define B=2] --suffix name
+        ds = [sys.argv[i + 1] for i, a in enumerate(sys.argv) if a == '--define']
+        build(shapes=shp, defines=ds, suffix=sys.argv[sys.argv.index('--suffix') + 1])
+        sys.exit(0)
     build(force='--force' in sys.argv, shapes=shp)
     if '--stamps' in sys.argv:
         build(stamps=True, shapes=shp)

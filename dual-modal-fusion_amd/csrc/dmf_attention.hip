@@ -533,13 +533,13 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       acc = AT_DPP(acc, 0xB1, AT_ADD); acc = AT_DPP(acc, 0x4E, AT_ADD);
       if (part == 0 && i < F2) {
         sDz[i] = acc;
-        a.ws_z[(size_t)b * F2 + i] = sZ[i];
+        a.ws_z[hv_index(b, i, a.B)] = sZ[i];
       }
       if (tid >= NT - 64) {                          // (the last wave has no dz column)
         const int j = tid - (NT - 64);
-        a.ws_h[(size_t)b * H + j] = sHd[j];
-        a.ws_dh[(size_t)b * H + j] = sDh[j];
-        a.ws_dl[(size_t)b * KMAX + j] = sDl[j];
+        a.ws_h[hv_index(b, j, a.B)] = sHd[j];
+        a.ws_dh[hv_index(b, j, a.B)] = sDh[j];
+        a.ws_dl[hv_index(b, j, a.B)] = sDl[j];
       }
     }
     __syncthreads();

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "dmf_kargs.h"
+#include "dmf_lanes.h"
 #include "dmf_xgmi.h"
 
 namespace dmf {
@@ -47,6 +48,7 @@ struct ReduceArgs {
   XgmiDev x;                          // x.world > 1: exchange the gradient with the peer ranks before Adam
   float grad_scale; int seq_bias;
   float* scaler;                      // loss-scaler state (dmf_grad_reduce_scaled): grad <- sum / scaler[0], non-finite -> scaler[2]
+  int dbg;                            // stamps build: probe switches (DMF_REDUCE_DBG)
 };
 
 // bias corrections from a device-resident step count, in double like torch's host-side scalars
@@ -68,131 +70,25 @@ __device__ __forceinline__ void adam_update(float* theta, float* m, float* v, in
   theta[p] -= (lr / bc1) * (mn / denom);
 }
 
-// Block layout: 16 consecutive parameters x 16 batch chunks (256 threads).  Every thread issues its chunk's loads
-// back to back (16 per pass), chunk partials are combined through LDS in a fixed tree, so the result does not
-// depend on scheduling.  The last block does the bookkeeping (per-step mean loss, epoch-plan cursor).
-__global__ __launch_bounds__(256) void grad_reduce_kernel_v1(const ReduceArgs a) {
-  __shared__ float part[16][17];
-  const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {                 // bookkeeping block
-    const int cur = a.cursor_dev != nullptr ? *a.cursor_dev : 0;
-    if (a.loss != nullptr && a.loss_hist != nullptr) {
-      float s = 0.f;
-      for (int b = tid; b < a.B; b += 256) s += a.loss[b];
-      float* red = &part[0][0];
-      red[tid] = s;
-      __syncthreads();
-      for (int w = 128; w > 0; w >>= 1) {
-        if (tid < w) red[tid] += red[tid + w];
-        __syncthreads();
-      }
-      if (tid == 0) a.loss_hist[cur] = red[0] / (float)a.B;
-    }
-    if (tid == 0 && a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
-    return;
-  }
-  const int jj = tid & 15, ch = tid >> 4;
-  const int64_t p = (int64_t)blockIdx.x * 16 + jj;
-  float acc = 0.f;
-  // the thread that will apply ADAM fetches its state now, so that latency overlaps the gradient reads
-  float th0 = 0.f, m0 = 0.f, v0 = 0.f;
-  if (ch == 0 && p < a.n && a.theta != nullptr) { th0 = a.theta[p]; m0 = a.m[p]; v0 = a.v[p]; }
-  if (p < a.n) {
-    if (p < a.NCONV || p >= a.oAttn) {
-      const bool att = p >= a.oAttn;
-      const float* sl = att ? a.aslab + (p - a.oAttn) : a.slab + p;
-      const int pitch = att ? a.ASLAB : a.SLAB, nb = att ? a.nablk : a.nblk;
-      const int per = (nb + 15) / 16;
-      const int lo = ch * per, hi = min(nb, lo + per);
-      for (int b0 = lo; b0 < hi; b0 += 16) {
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (b0 + i < hi) ? sl[(size_t)(b0 + i) * pitch] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc += v[i];
-      }
-    } else {
-      const int per = (a.B + 15) / 16;
-      const int lo = ch * per, hi = min(a.B, lo + per);
-      const float* u; const float* w; int su, sw, ou, ow;   // acc += u[b*su + ou] * w[b*sw + ow]  (w == nullptr: * 1)
-      if (p < a.oFc1b) {
-        const int q = (int)(p - a.oFc1w), j = q / a.F2, i = q - j * a.F2;
-        u = a.dh; su = a.H; ou = j; w = a.z; sw = a.F2; ow = i;
-      } else if (p < a.oFc2w) {
-        u = a.dh; su = a.H; ou = (int)(p - a.oFc1b); w = nullptr; sw = 0; ow = 0;
-      } else if (p < a.oFc2b) {
-        const int q = (int)(p - a.oFc2w), k = q / a.H, j = q - k * a.H;
-        u = a.dl; su = KMAX; ou = k; w = a.h; sw = a.H; ow = j;
-      } else {
-        u = a.dl; su = KMAX; ou = (int)(p - a.oFc2b); w = nullptr; sw = 0; ow = 0;
-      }
-      for (int b0 = lo; b0 < hi; b0 += 16) {
-        float x[16], y[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bool in = b0 + i < hi;
-          x[i] = in ? u[(size_t)(b0 + i) * su + ou] : 0.f;
-          y[i] = (w != nullptr) ? (in ? w[(size_t)(b0 + i) * sw + ow] : 0.f) : 1.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc = fmaf(x[i], y[i], acc);
-      }
-    }
-  }
-  part[ch][jj] = acc;
-  __shared__ float bcs[2];
-  if (tid == 255 && a.theta != nullptr) {            // one thread per block forms the bias corrections
-    float bc1 = a.bc1, bc2s = a.bc2_sqrt;
-    if (a.step_dev != nullptr) bias_corrections(*a.step_dev, a.b1, a.b2, bc1, bc2s);
-    bcs[0] = bc1;
-    bcs[1] = bc2s;
-  }
-  __syncthreads();
-  float g = 0.f;
-  if (ch == 0 && p < a.n) {
-    float t[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = part[i][jj];
-#pragma unroll
-    for (int w = 8; w > 0; w >>= 1)
-#pragma unroll
-      for (int i = 0; i < w; ++i) t[i] += t[i + w];
-    g = t[0];
-  }
-  if (a.x.world > 1)                                 // block-uniform: every thread takes part in the barriers
-    g = xgmi_exchange(a.x, 0, *a.step_dev + a.seq_bias, blockIdx.x, p, ch == 0 && p < a.n, g) * a.grad_scale;
-  if (a.scaler != nullptr && ch == 0 && p < a.n) {     // unscale_ + the found_inf check of GradScaler, in the reduce
-    g *= 1.f / a.scaler[0];
-    if (!isfinite(g)) a.scaler[2] = 1.f;               // (every writer stores the same value)
-  }
-  if (ch == 0 && p < a.n) {
-    if (a.grad != nullptr) a.grad[p] = g;
-    if (a.theta != nullptr) {
-      const float mn = m0 + (g - m0) * (1.f - a.b1);
-      const float vn = v0 * a.b2 + (1.f - a.b2) * g * g;
-      a.m[p] = mn;
-      a.v[p] = vn;
-      a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
-    }
-  }
-}
-
-// ---- the reduce launch, second form (round 3).  Same sums in the same ORDER as the first form (rows / batch entries cut
-// into 16 chunks, each chunk summed front to back, the 16 partials combined by the fixed tree ((0+8)+(4+12)) + ((2+10)+(6+14))
-// + ... ), so every gradient bit is unchanged; what changed is who reads what:
-//   * conv (and attention) slabs: a block owns 64 consecutive parameters, a thread reads 16-byte pieces — a wave instruction
-//     covers four 256-byte row segments instead of four 64-byte ones, 27 blocks instead of 108 for the 200-band net;
-//   * fc1.weight / fc2.weight = dh^T z / dl^T h: one 16x16 output tile per block on the fp32 matrix cores
-//     (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered fmaf chain).  Wave w carries chunks w, w+4, w+8, w+12 in four
-//     accumulators; z / dh / h / dl are read ONCE per tile instead of once per parameter (the first form issued 41 K
-//     wave-level loads for them, this one 2.6 K);
-//   * the two bias vectors keep the first form's mapping (16 parameters x 16 chunks per block);
-//   * ADAM's bias corrections: b^step by repeated squaring in double on two lanes (beta1 / beta2 side by side) under the
-//     gradient loads, instead of two calls of the general pow() on one lane in front of the barrier.
-// Block order: fc tiles first (the longest chains), then slabs, biases, and the bookkeeping block last.
+// ---- the reduce launch.  What bounds it (tools/reduce_phase_profile.py, stamps of round 3): ONE CU takes in only ~15 bytes
+// per clock from the Infinity Cache (about 64 lines in flight x ~550 cycles), and the 2.2 MB the patch kernel left behind are
+// nowhere else.  The first forms (16 or 64 parameters per block, 64-byte pieces of 7-KB rows, 64 KB fetched per block) spent
+// 4.5 K of their 6.8 K cycles waiting for that; so the producers now lay their results out for THIS kernel (dmf_shapes.h):
+//   * conv slabs piece-major: one block per 16 parameters reads rows x 64 contiguous bytes (16 KB at batch 256) — a lane
+//     holds one 16-byte piece of up to 4 rows, rows are summed per lane, then over the 16 row lanes by DPP and the row /
+//     half swaps, then over the 4 waves through LDS: a fixed order;
+//   * fc1.weight / fc2.weight = dh^T z / dl^T h: one 8x8 output tile per block — 2 x 8 KB of contiguous strip-major head
+//     vectors at batch 256 (a 16x16 tile needs 2 x 16 KB: twice the wait).  It still runs on the fp32 matrix cores
+//     (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered fmaf chain) with the two HALVES of the batch packed into one
+//     instruction: rows 0-7 / columns 0-7 carry the first half, rows 8-15 / columns 8-15 the second, the two diagonal 8x8
+//     blocks of the result are the two partial tiles (the off-diagonal blocks are discarded); wave w carries a quarter of each
+//     half in two accumulators.  The tiles of the first column also sum their dh / dl strip: fc1.bias / fc2.bias;
+//   * attention slabs keep the row-major form (64 parameters per block): 15.7 MB per step, bound by the chip, not the CU;
+//   * ADAM's bias corrections: b^step by repeated squaring in double on two lanes of a fifth wave (beta1 / beta2 side by
+//     side) beside the gradient loads, instead of two calls of the general pow() on one lane in front of the barrier.
+// Block order: fc tiles first (the longest chains), then slabs, the bookkeeping block last.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-struct ReducePlan { int nFc1, t1n, nFc2, nConv, nAttn, nBias; };   // blocks per kind (host and device agree through ReduceArgs)
 
 __device__ __forceinline__ double powi_double(double b, int n) {   // b^n, n >= 0, by squaring (relative error ~ 2 log2(n) ulp)
   double r = 1.0;
@@ -204,7 +100,7 @@ __device__ __forceinline__ double powi_double(double b, int n) {   // b^n, n >= 
   return r;
 }
 
-// the fixed combine of 16 chunk partials (see above)
+// the fixed combine of 16 chunk partials ((0+8)+(4+12)) + ... (attention slabs)
 __device__ __forceinline__ float tree16(float (&t)[16]) {
 #pragma unroll
   for (int w = 8; w > 0; w >>= 1)
@@ -213,45 +109,78 @@ __device__ __forceinline__ float tree16(float (&t)[16]) {
   return t[0];
 }
 
-// partial of one 16 x 16 tile of out[m][n] = sum_b U[b * su + m0 + m] * W[b * sw + n0 + n]: wave w's chunks, written to
-// vbuf[w] in output order (row * 16 + column).  Rows >= mlim / columns >= nlim read as zero.  Threads 0..255.
-__device__ __forceinline__ void fc_tile_partial(const float* __restrict__ U, int su, int m0, int mlim, const float* __restrict__ W,
-                                                int sw, int n0, int nlim, int B, float (*vbuf)[256]) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int mn = lane & 15, kk = lane >> 4;
-  const bool mok = m0 + mn < mlim, nok = n0 + mn < nlim;
-  const float* up = U + m0 + mn;
-  const float* wp = W + n0 + mn;
-  const int per = (B + 15) / 16, nq = (per + 3) / 4;
-  f32x4_t acc[4];
+// One 8 x 8 tile of out[m][n] = sum_b U[b][m0 + m] * W[b][n0 + n] (U, W strip-major: hv_index; m0, n0 multiples of 8).
+// MFMA row / column q < 8 works on the patches [0, Bh), q >= 8 on [Bh, B); wave w takes a quarter of each half's k-steps (4
+// patches each), 8 steps per batch.  issue(): the 16 loads of one batch; consume(): its 8 MFMAs (two accumulators) and the
+// running sum of the U operand (the bias gradient).  Rows >= mlim read as zero.  Threads 0..255.
+struct FcTile {
+  const float* up; const float* wp;
+  int bbase, blim, kk, s1, sb_;
+  bool mok;
+  f32x4_t acc0, acc1;
+  float bs;
+  float av[8], bv[8];
+  __device__ __forceinline__ int init(const float* U, int m0, int mlim, const float* W, int n0, int B) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q8 = lane & 7, half = (lane >> 3) & 1;
+    kk = lane >> 4;
+    mok = m0 + q8 < mlim;
+    const int Bh = (((B + 1) >> 1) + 3) & ~3;                 // first half: a multiple of 4 patches
+    bbase = half ? Bh : 0; blim = half ? B : min(Bh, B);
+    up = U + (size_t)(m0 >> 3) * B * 8 + q8;                  // strip m0 / 8: element (b, m) at b * 8 + m
+    wp = W + (size_t)(n0 >> 3) * B * 8 + q8;
+    const int nk = Bh / 4, nkw = (nk + 3) / 4;                // k-steps per half: all, per wave
+    const int s0 = w * nkw;
+    s1 = min(nk, s0 + nkw);
+    acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc1 = acc0; bs = 0.f;
+    return s0;
+  }
+  // (loads are UNCONDITIONAL, from a clamped patch index, and masked in consume(): a load under a lane condition becomes a
+  // branch around it, and the compiler then waits for the loads of one branch before it enters the next)
+  __device__ __forceinline__ void issue(int sb) {
 #pragma unroll
-  for (int ci = 0; ci < 4; ++ci) acc[ci] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int q0 = 0; q0 < nq; q0 += 4) {
-    float av[4][4], bv[4][4];
+    for (int q = 0; q < 8; ++q) {
+      const int b = min(bbase + 4 * (sb + q) + kk, blim - 1);
+      av[q] = up[(size_t)(b < 0 ? 0 : b) * 8];
+      bv[q] = wp[(size_t)(b < 0 ? 0 : b) * 8];
+    }
+    sb_ = sb;
+  }
+  __device__ __forceinline__ void consume() {
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-      const int lo = (w + 4 * ci) * per, hi = min(B, lo + per);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int b = lo + 4 * (q0 + qq) + kk;
-        const bool in = q0 + qq < nq && b < hi;
-        av[ci][qq] = (in && mok) ? up[(size_t)b * su] : 0.f;
-        bv[ci][qq] = (in && nok) ? wp[(size_t)b * sw] : 0.f;
-      }
+    for (int q = 0; q < 8; ++q) {
+      const bool in = sb_ + q < s1 && bbase + 4 * (sb_ + q) + kk < blim;
+      av[q] = (in && mok) ? av[q] : 0.f;
+      bv[q] = in ? bv[q] : 0.f;
     }
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq)
+    for (int q = 0; q < 8; q += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], bv[q + 1], acc1, 0, 0, 0);
+    }
 #pragma unroll
-      for (int ci = 0; ci < 4; ++ci) acc[ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ci][qq], bv[ci][qq], acc[ci], 0, 0, 0);
+    for (int q = 0; q < 8; ++q) bs += av[q];
   }
-  const f32x4_t u0 = acc[0] + acc[2], u1 = acc[1] + acc[3], v = u0 + u1;   // chunks (w + w+8) + (w+4 + w+12)
-#pragma unroll
-  for (int r = 0; r < 4; ++r) vbuf[w][(4 * kk + r) * 16 + mn] = v[r];      // C layout: row 4 (lane >> 4) + r, column lane & 15
+};
+
+__device__ __forceinline__ void adam_apply(const ReduceArgs& a, int64_t p, float g, float th0, float m_0, float v_0, const float* bcs) {
+  if (a.scaler != nullptr) {                         // unscale_ + the found_inf check of GradScaler, in the reduce
+    g *= 1.f / a.scaler[0];
+    if (!isfinite(g)) a.scaler[2] = 1.f;             // (every writer stores the same value)
+  }
+  if (a.grad != nullptr) a.grad[p] = g;
+  if (a.theta != nullptr) {
+    const float mn = m_0 + (g - m_0) * (1.f - a.b1);
+    const float vn = v_0 * a.b2 + (1.f - a.b2) * g * g;
+    a.m[p] = mn;
+    a.v[p] = vn;
+    a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
+  }
 }
 
 // Diagnostic build only (-DDMF_STAMPS, tools/reduce_phase_profile.py): clock stamps of every wave of the reduce launch in
-// scalar registers, dumped by lane 0 right before the wave ends.  [block][5 waves][8]: 0 entry, 1 role known (kernarg), 2 loads
-// issued, 3 partials written (loads landed), 4 behind the barrier, 5 stores issued, 6 end; 7 s_memrealtime at entry.
+// scalar registers, dumped by lane 0 right before the wave ends.  [block][5 waves][8]: 0 entry, 2 kernel arguments in registers, 1 role known, 3 partials
+// written (loads landed), 4 behind the barrier, 5 stores issued, 6 end; 7 s_memrealtime at entry.
 #ifdef DMF_STAMPS
 __device__ unsigned long long* g_rstamps = nullptr;
 #define RSTAMP_DECL unsigned long long rst_[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
@@ -268,15 +197,26 @@ __device__ unsigned long long* g_rstamps = nullptr;
 #endif
 
 // 320 threads: waves 0-3 reduce, wave 4 only forms ADAM's bias corrections (beside the other waves' gradient loads).
-__global__ __launch_bounds__(320) void grad_reduce_kernel(const ReduceArgs a, const ReducePlan pl) {
-  __shared__ float vbuf[4][256];        // tile partials of the four waves / [16 chunks][64] slab partials / [16][16] bias partials
+// The first nine arguments are everything a block needs to find its role and ISSUE its gradient loads; they are plain scalars
+// in front of the argument struct so that the compiler's kernarg preload (-mllvm -amdgpu-kernarg-preload-count, build.py) puts
+// them into scalar registers at wave launch: a kernel argument fetched by the wave itself arrives ~1.0 K cycles after wave
+// entry (stamps), and every load of this kernel was waiting behind that.  w0 = nFc1 | t1n << 16, w1 = nFc2 | t2n << 16,
+// w2 = nConv | nAttn << 16 (blocks per kind, tiles per row).
+__global__ __launch_bounds__(320) void grad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ dh,
+                                                          const float* __restrict__ z, const float* __restrict__ dl,
+                                                          const float* __restrict__ h, int w0, int w1, int w2, int B, const ReduceArgs a) {
+  __shared__ float vbuf[4][256];        // tile partials of the four waves / [16 chunks][64] attention-slab partials / [4][16] piece partials
+  __shared__ float bbuf[4][16];         // bias partials of the four waves
   __shared__ float bcs[2];
   const int tid = threadIdx.x;
   int blk = blockIdx.x;
   RSTAMP_DECL;
   RSTAMP_RT(7);
   RSTAMP(0);
-  if (blk == (int)gridDim.x - 1) {                   // bookkeeping block
+  const int nFc1 = w0 & 0xffff, t1n = w0 >> 16, nFc2 = w1 & 0xffff, t2n = w1 >> 16, nConv = w2 & 0xffff, nAttn = w2 >> 16;
+  const int nTotal = nFc1 + nFc2 + nConv + nAttn + 1;
+  const int nblk = B < MAX_BLOCKS ? B : MAX_BLOCKS;  // slab rows: the patch kernel's grid
+  if (blk == nTotal - 1) {                           // bookkeeping block
     const int cur = a.cursor_dev != nullptr ? *a.cursor_dev : 0;
     if (a.loss != nullptr && a.loss_hist != nullptr) {
       float s = 0.f;
@@ -295,42 +235,63 @@ __global__ __launch_bounds__(320) void grad_reduce_kernel(const ReduceArgs a, co
     if (tid == 0 && a.cursor_dev != nullptr) *a.cursor_dev = cur + 1;
     return;
   }
-  // ---- which parameter this thread finishes (p, own) — known before any gradient is read, so that the ADAM state is requested first
-  int kind, sub;                                     // 0 fc1.weight tile, 1 fc2.weight tile, 2 conv slab, 3 attention slab, 4 biases
-  if (blk < pl.nFc1) { kind = 0; sub = blk; }
-  else if ((blk -= pl.nFc1) < pl.nFc2) { kind = 1; sub = blk; }
-  else if ((blk -= pl.nFc2) < pl.nConv) { kind = 2; sub = blk; }
-  else if ((blk -= pl.nConv) < pl.nAttn) { kind = 3; sub = blk; }
-  else { kind = 4; sub = blk - pl.nAttn; }
-  int64_t p = 0;
-  bool own = false;
+  int kind, sub;                                     // 0 fc1.weight tile, 1 fc2.weight tile, 2 conv slab piece, 3 attention slab
+  if (blk < nFc1) { kind = 0; sub = blk; }
+  else if ((blk -= nFc1) < nFc2) { kind = 1; sub = blk; }
+  else if ((blk -= nFc2) < nConv) { kind = 2; sub = blk; }
+  else { kind = 3; sub = blk - nConv; }
+  // ---- the first batch of gradient loads goes out before anything else is looked at
   int m0 = 0, n0 = 0;
+  FcTile ft;
+  int sb = 0;
+  float4 cv[4];
+  const int lane = tid & 63, wv = tid >> 6, c4 = lane & 3, r16 = lane >> 2;
+  const float* csrc = slab + (size_t)sub * nblk * 16 + 4 * c4;       // conv piece `sub` of every row: rows x 16 floats, contiguous
+  if (kind < 2) {
+    const int tn = kind == 0 ? t1n : t2n;
+    const int mt = (int)((float)sub / (float)tn + 0.01f);            // (exact for the few hundred tiles there are)
+    m0 = 8 * mt; n0 = 8 * (sub - mt * tn);
+    if (tid < 256) {
+      sb = kind == 0 ? ft.init(dh, m0, a.H, z, n0, B) : ft.init(dl, m0, a.K, h, n0, B);
+      ft.issue(sb);
+    }
+  } else if (kind == 2 && tid < 256) {
+    // lane = (16-byte quarter c4, row lane r16); wave wv, load i: rows (4 i + wv) * 16 + r16 — every wave-level load is 1 KiB
+    // of contiguous bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i)                          // (unconditional, clamped row; masked where they are summed)
+      cv[i] = *reinterpret_cast<const float4*>(csrc + (size_t)min((4 * i + wv) * 16 + r16, nblk - 1) * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);                 // (nothing that waits for these loads may move up here)
+  RSTAMP(2);
+  // ---- which parameter(s) this thread finishes (p, own; p2, own2: the bias of a first-column tile), and their ADAM state
+  int64_t p = 0, p2 = 0;
+  bool own = false, own2 = false;
   if (kind == 0) {
-    m0 = 16 * (sub / pl.t1n); n0 = 16 * (sub % pl.t1n);
-    const int j = m0 + (tid >> 4), i = n0 + (tid & 15);
-    own = j < a.H && i < a.F2;
+    const int j = m0 + ((tid >> 3) & 7), i = n0 + (tid & 7);
+    own = tid < 64 && j < a.H && i < a.F2;
     p = a.oFc1w + (int64_t)j * a.F2 + i;
+    own2 = n0 == 0 && tid < 8 && m0 + tid < a.H;
+    p2 = a.oFc1b + m0 + tid;
   } else if (kind == 1) {
-    const int t2n = a.H / 16;
-    m0 = 16 * (sub / t2n); n0 = 16 * (sub % t2n);
-    const int k = m0 + (tid >> 4), j = n0 + (tid & 15);
-    own = k < a.K && j < a.H;
+    const int k = m0 + ((tid >> 3) & 7), j = n0 + (tid & 7);
+    own = tid < 64 && k < a.K && j < a.H;
     p = a.oFc2w + (int64_t)k * a.H + j;
+    own2 = n0 == 0 && tid < 8 && m0 + tid < a.K;
+    p2 = a.oFc2b + m0 + tid;
   } else if (kind == 2) {
-    p = (int64_t)64 * sub + tid;
-    own = tid < 64 && p < a.NCONV;
-  } else if (kind == 3) {
+    p = (int64_t)16 * sub + tid;
+    own = tid < 16 && p < a.NCONV;
+  } else {
     p = a.oAttn + (int64_t)64 * sub + tid;
     own = tid < 64 && 64 * sub + tid < a.ASLAB;
-  } else {
-    const int q = 16 * sub + tid;
-    own = tid < 16 && q < a.H + a.K;
-    p = q < a.H ? a.oFc1b + q : a.oFc2b + (q - a.H);
   }
-  own = own && tid < 256;
   RSTAMP(1);
-  float th0 = 0.f, m_0 = 0.f, v_0 = 0.f;
-  if (own && a.theta != nullptr) { th0 = a.theta[p]; m_0 = a.m[p]; v_0 = a.v[p]; }
+  float th0 = 0.f, m_0 = 0.f, v_0 = 0.f, th2 = 0.f, m_2 = 0.f, v_2 = 0.f;
+  if (a.theta != nullptr) {
+    if (own) { th0 = a.theta[p]; m_0 = a.m[p]; v_0 = a.v[p]; }
+    if (own2) { th2 = a.theta[p2]; m_2 = a.m[p2]; v_2 = a.v[p2]; }
+  }
   float* part = &vbuf[0][0];
   if (tid >= 256) {
     // bias corrections (lanes 0 / 1 of wave 4: beta1 / beta2 side by side), b^step by repeated squaring in double
@@ -342,16 +303,43 @@ __global__ __launch_bounds__(320) void grad_reduce_kernel(const ReduceArgs a, co
       }
       bcs[tid - 256] = bc;
     }
-  } else if (kind == 0) {
-    fc_tile_partial(a.dh, a.H, m0, a.H, a.z, a.F2, n0, a.F2, a.B, vbuf);
-  } else if (kind == 1) {
-    fc_tile_partial(a.dl, KMAX, m0, a.K, a.h, a.H, n0, a.H, a.B, vbuf);
-  } else if (kind == 2 || kind == 3) {
-    const bool att = kind == 3;
-    const int pitch = att ? a.ASLAB : a.SLAB, nb = att ? a.nablk : a.nblk;
-    const int c4 = tid & 15, ch = tid >> 4;
-    const bool in_row = 64 * sub + 4 * c4 < pitch;
-    const float* sl = (att ? a.aslab : a.slab) + 64 * sub + 4 * c4;
+  } else if (kind < 2) {
+    ft.consume();
+    for (sb += 8; sb < ft.s1; sb += 8) { ft.issue(sb); ft.consume(); }
+    const f32x4_t v = ft.acc0 + ft.acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vbuf[wv][(4 * ft.kk + r) * 16 + (lane & 15)] = v[r];   // C layout: row 4 (lane >> 4) + r, column lane & 15
+    const float bias = swap_add32(swap_add16(ft.bs));                                  // over the four k lanes of a row
+    if (lane < 16) bbuf[wv][lane] = bias;                                              // [wave][half * 8 + row]
+  } else if (kind == 2) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0;;) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = (4 * (i0 + i) + wv) * 16 + r16 < nblk;
+        acc.x += in ? cv[i].x : 0.f; acc.y += in ? cv[i].y : 0.f; acc.z += in ? cv[i].z : 0.f; acc.w += in ? cv[i].w : 0.f;
+      }
+      i0 += 4;
+      if ((4 * i0 + wv) * 16 >= nblk) break;                           // (more than 256 rows: not with today's MAX_BLOCKS)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        cv[i] = *reinterpret_cast<const float4*>(csrc + (size_t)min((4 * (i0 + i) + wv) * 16 + r16, nblk - 1) * 16);
+    }
+    // over the 16 row lanes (lane bits 2..5): xor 4 / xor 8 inside a 16-lane row by row rotations, then the row / half swaps
+    float e[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = e[k];
+      x = DMF_DPP_ADD(x, 0x124);     // row_ror:4
+      x = DMF_DPP_ADD(x, 0x128);     // row_ror:8
+      e[k] = swap_add32(swap_add16(x));
+    }
+    if (lane < 4) *reinterpret_cast<float4*>(part + wv * 16 + 4 * c4) = make_float4(e[0], e[1], e[2], e[3]);
+  } else {
+    const int pitch = a.ASLAB, nb = a.nablk;
+    const int q4 = tid & 15, ch = tid >> 4;
+    const bool in_row = 64 * sub + 4 * q4 < pitch;
+    const float* sl = a.aslab + 64 * sub + 4 * q4;
     const int per = (nb + 15) / 16;
     const int lo = ch * per, hi = min(nb, lo + per);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -363,58 +351,36 @@ __global__ __launch_bounds__(320) void grad_reduce_kernel(const ReduceArgs a, co
 #pragma unroll
       for (int i = 0; i < 16; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
     }
-    *reinterpret_cast<float4*>(part + ch * 64 + 4 * c4) = acc;          // [16 chunks][64]
-  } else {
-    const int jj = tid & 15, ch = tid >> 4, q = 16 * sub + jj;
-    const int per = (a.B + 15) / 16;
-    const int lo = ch * per, hi = min(a.B, lo + per);
-    float acc = 0.f;
-    if (q < a.H + a.K) {
-      const float* u = q < a.H ? a.dh + q : a.dl + (q - a.H);
-      const int su = q < a.H ? a.H : KMAX;
-      for (int b0 = lo; b0 < hi; b0 += 16) {
-        float x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = (b0 + i < hi) ? u[(size_t)(b0 + i) * su] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc += x[i];
-      }
-    }
-    part[ch * 16 + jj] = acc;                                           // [16 chunks][16]
+    *reinterpret_cast<float4*>(part + ch * 64 + 4 * q4) = acc;          // [16 chunks][64]
   }
   RSTAMP(3);
   __syncthreads();
   RSTAMP(4);
-  float g = 0.f;
+  float g = 0.f, g2 = 0.f;
   if (tid < 256) {
     if (kind < 2) {
-      g = (vbuf[0][tid] + vbuf[2][tid]) + (vbuf[1][tid] + vbuf[3][tid]);
-    } else if (tid < 64) {
-      const int stride = kind == 4 ? 16 : 64;
-      if (kind != 4 || tid < 16) {
-        float t[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = part[i * stride + tid];
-        g = tree16(t);
+      if (tid < 64) {                                  // the two diagonal blocks of every wave's result, in wave order
+        const int e0 = (tid >> 3) * 16 + (tid & 7), e1 = e0 + 8 * 16 + 8;
+        g = ((vbuf[0][e0] + vbuf[0][e1]) + (vbuf[1][e0] + vbuf[1][e1])) + ((vbuf[2][e0] + vbuf[2][e1]) + (vbuf[3][e0] + vbuf[3][e1]));
       }
+      if (tid < 8) g2 = ((bbuf[0][tid] + bbuf[0][8 + tid]) + (bbuf[1][tid] + bbuf[1][8 + tid])) +
+                        ((bbuf[2][tid] + bbuf[2][8 + tid]) + (bbuf[3][tid] + bbuf[3][8 + tid]));
+    } else if (kind == 2) {
+      if (tid < 16) g = (part[tid] + part[16 + tid]) + (part[32 + tid] + part[48 + tid]);
+    } else if (tid < 64) {
+      float t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = part[i * 64 + tid];
+      g = tree16(t);
     }
   }
-  if (a.x.world > 1)                                 // block-uniform: every thread takes part in the barriers
-    g = xgmi_exchange(a.x, 0, *a.step_dev + a.seq_bias, blockIdx.x, p, own, g) * a.grad_scale;
-  if (own) {
-    if (a.scaler != nullptr) {                       // unscale_ + the found_inf check of GradScaler, in the reduce
-      g *= 1.f / a.scaler[0];
-      if (!isfinite(g)) a.scaler[2] = 1.f;           // (every writer stores the same value)
-    }
-    if (a.grad != nullptr) a.grad[p] = g;
-    if (a.theta != nullptr) {
-      const float mn = m_0 + (g - m_0) * (1.f - a.b1);
-      const float vn = v_0 * a.b2 + (1.f - a.b2) * g * g;
-      a.m[p] = mn;
-      a.v[p] = vn;
-      a.theta[p] = th0 - (a.lr / bcs[0]) * (mn / (sqrtf(vn) / bcs[1] + a.eps));
-    }
+  if (a.x.world > 1) {                               // block-uniform: every thread takes part in the barriers
+    const int seq = *a.step_dev + a.seq_bias;
+    g = xgmi_exchange(a.x, 0, seq, blockIdx.x, p, own, g) * a.grad_scale;
+    if (kind < 2 && n0 == 0) g2 = xgmi_exchange(a.x, 0, seq, nTotal + blockIdx.x, p2, own2, g2) * a.grad_scale;
   }
+  if (own) adam_apply(a, p, g, th0, m_0, v_0, bcs);
+  if (own2) adam_apply(a, p2, g2, th2, m_2, v_2, bcs);
   RSTAMP(5);
   RSTAMP_DUMP();
 }
@@ -874,29 +840,25 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
   a.step_dev = step_dev; a.cursor_dev = cursor_dev; a.loss = loss; a.loss_hist = loss_hist;
   a.grad_scale = grad_scale;
   a.scaler = scaler;
+#ifdef DMF_STAMPS
+  { const char* e = getenv("DMF_REDUCE_DBG"); a.dbg = e != nullptr ? atoi(e) : 0; }
+#endif
   if (comm != nullptr) {
     if (step_dev == nullptr) return fail("%s", "the xgmi exchange needs adam_step_dev");
     if (comm->capacity < L.n_params) return fail("%s", "xgmi communicator smaller than the parameter vector");
     if (fill_xgmi(comm, a.x)) return 1;
     a.seq_bias = comm->seq_bias;
   }
-  const char* e_v1 = getenv("DMF_REDUCE_V1");             // (temporary A/B switch: the first form of the kernel)
-  if (e_v1 != nullptr && e_v1[0] == '1') {
-    const int grid = (int)((L.n_params + 15) / 16) + 1;   // + the bookkeeping block
-    hipLaunchKernelGGL(grad_reduce_kernel_v1, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    return check(hipGetLastError(), "grad_reduce launch");
-  }
-  if (L.H % 16 != 0) return fail("%s", "grad_reduce: hidden width must be a multiple of 16");
-  ReducePlan pl{};
-  pl.t1n = (L.F2 + 15) / 16;
-  pl.nFc1 = (L.H / 16) * pl.t1n;
-  pl.nFc2 = ((L.K + 15) / 16) * (L.H / 16);
-  pl.nConv = (L.NCONV + 63) / 64;
-  pl.nAttn = L.attention ? (a.ASLAB + 63) / 64 : 0;
-  pl.nBias = (L.H + L.K + 15) / 16;
-  const int grid = pl.nFc1 + pl.nFc2 + pl.nConv + pl.nAttn + pl.nBias + 1;   // + the bookkeeping block
-  if (comm != nullptr && grid > a.x.nblk) return fail("%s", "xgmi communicator has fewer block flags than the reduce grid");
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(320), 0, static_cast<hipStream_t>(stream), a, pl);
+  if (L.H % 8 != 0 || L.F2 % 8 != 0) return fail("%s", "grad_reduce: hidden width and 2 x gmf.width must be multiples of 8");
+  const int t1n = L.F2 / 8, t2n = L.H / 8;
+  const int nFc1 = (L.H / 8) * t1n, nFc2 = ((L.K + 7) / 8) * t2n, nConv = (L.NCONV + 15) / 16;
+  const int nAttn = L.attention ? (a.ASLAB + 63) / 64 : 0;
+  if (nFc1 > 0xffff || nFc2 > 0xffff || nConv > 0xffff || nAttn > 0x7fff) return fail("%s", "grad_reduce: too many blocks of one kind");
+  const int grid = nFc1 + nFc2 + nConv + nAttn + 1;   // + the bookkeeping block
+  // (the exchange keeps one flag per block; the bias sums of the first-column tiles use a second flag index behind the grid's)
+  if (comm != nullptr && 2 * grid > a.x.nblk) return fail("%s", "xgmi communicator has fewer block flags than the reduce grid needs");
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(320), 0, static_cast<hipStream_t>(stream), a.slab, a.dh, a.z, a.dl, a.h,
+                     nFc1 | (t1n << 16), nFc2 | (t2n << 16), nConv | (nAttn << 16), B, a);
   return check(hipGetLastError(), "grad_reduce launch");
 }
 

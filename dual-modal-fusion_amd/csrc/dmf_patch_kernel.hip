@@ -420,7 +420,8 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
   cfloat* thc = (cfloat*)a.theta;
   const int K = a.K;
   const int B = a.in.B;
-  float* __restrict__ slab = a.slab + (size_t)blockIdx.x * Sh::SLAB;
+  // this workgroup's slab row, piece-major (dmf_shapes.h): element p lives at a.slab[slab_index(blockIdx.x, p, gridDim.x)]
+  auto slab_at = [&](int p) -> float* { return a.slab + slab_index(blockIdx.x, p, gridDim.x); };
 
   STAMP(11);
   // Prologue.  The patch-invariant tables (pooling profile, depthwise taps, fc2 rows) are fetched into registers
@@ -738,10 +739,11 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
     }
     if (MODE == MODE_FWD) continue;       // (the next patch's gather is fenced by its own barriers)
     if (wave == Sh::NW - 1) {
-      a.ws_h[(size_t)b * Sh::H + lane] = sH[lane];
-      a.ws_dh[(size_t)b * Sh::H + lane] = sDh[lane];
-      a.ws_dl[(size_t)b * KMAX + lane] = sDl[lane];
-      for (int i = lane; i < Sh::F2; i += 64) a.ws_z[(size_t)b * Sh::F2 + i] = sZ[i];
+      const size_t hv = hv_index(b, lane, B);            // strip-major head vectors (dmf_shapes.h)
+      a.ws_h[hv] = sH[lane];
+      a.ws_dh[hv] = sDh[lane];
+      a.ws_dl[hv] = sDl[lane];
+      for (int i = lane; i < Sh::F2; i += 64) a.ws_z[hv_index(b, i, B)] = sZ[i];
     }
     {   // dz[i] = sum_j W1[j][i] dh[j]: 8 rows of a wave by DPP / permlane swaps (lane stride 8), waves in fixed order
       const float dh = (jH < Sh::H) ? sDh[jH] : 0.f;
@@ -787,11 +789,11 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const int oa = Sh::oA2w + fS * 9 + k, ob = Sh::oB2w + fS * 9 + k;
-          slab_put(slab + (oa), first, dwa[k]);
-          slab_put(slab + (ob), first, dwb[k]);
+          slab_put(slab_at(oa), first, dwa[k]);
+          slab_put(slab_at(ob), first, dwb[k]);
         }
-        slab_put(slab + (Sh::oA2b + fS), first, dba);
-        slab_put(slab + (Sh::oB2b + fS), first, dbb);
+        slab_put(slab_at(Sh::oA2b + fS), first, dba);
+        slab_put(slab_at(Sh::oB2b + fS), first, dbb);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -827,12 +829,12 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
       for (int q = 0; q < Sh::TB; ++q) dwl[q] = sum16(dwl[q]);
       if (spat && rS == 0) {
-        slab_put(slab + (Sh::oA1b + fS), first, ga);
-        slab_put(slab + (Sh::oB1b + fS), first, gb);
+        slab_put(slab_at(Sh::oA1b + fS), first, ga);
+        slab_put(slab_at(Sh::oB1b + fS), first, gb);
 #pragma unroll
         for (int q = 0; q < Sh::TB; ++q) {
           const int o = Sh::oB1w + fS * Sh::TB + q;
-          slab_put(slab + (o), first, dwl[q]);
+          slab_put(slab_at(o), first, dwl[q]);
         }
       }
     }
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
             sacc += pbase[(e / L::PW) * L::Cs + (e % L::PW)];
           }
           const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
-          slab_put(slab + (o), first, sacc);
+          slab_put(slab_at(o), first, sacc);
         }
       } else {
       float* scr = L::OWN_SLICE ? (sX + g * Sh::Cg) : (sGscr + blk * (NSLW * 4 * Sh::Cg));
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(Sh::NT) void patch_kernel(const KArgs a) {
 #pragma unroll
         for (int q = 0; q < NSLW; ++q) sacc += scr[(q * 4 + m) * SROW + j];
         const int o = Sh::oA1w + (4 * blk + m) * Sh::Cg + j;
-        slab_put(slab + (o), first, sacc);
+        slab_put(slab_at(o), first, sacc);
       }
       }   // aligned groups
     }

@@ -1,6 +1,7 @@
 // Compile-time geometry of one GMFNet instance + the flat parameter / workspace layouts shared by
 // host and device code.  (The architecture itself is stated in oracle/gmfnet_ref.py and DESIGN.md §2.)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace dmf {
@@ -76,6 +77,20 @@ inline Layout make_layout(int C, int C2, int P, int S, int F, int G, int H, int 
   L.n_params = o;
   return L;
 }
+
+// Layouts INSIDE the workspace regions (round 3; the reduce launch is bound by what ONE CU can fetch, ~15 B/clk from the
+// Infinity Cache, so every reader block must get a small CONTIGUOUS share):
+//   slab rows    piece-major  [SLAB/16 pieces][rows][16]: the 16 parameters of a piece from all workgroups are contiguous
+//                (rows x 64 B), one reduce block per piece reads them with full-line requests;
+//   head vectors strip-major  [W/8 strips][B][8] (W = 2F, H, H, KMAX): an 8-wide strip of all patches is contiguous (B x 32 B),
+//                which is exactly one operand of an 8x8 weight-gradient tile of the reduce launch.
+#if defined(__HIPCC__) || defined(__HIP__)
+#define DMF_HD __host__ __device__
+#else
+#define DMF_HD
+#endif
+DMF_HD inline size_t slab_index(int row, int p, int rows) { return ((size_t)(p >> 4) * rows + row) * 16 + (p & 15); }
+DMF_HD inline size_t hv_index(int b, int i, int B) { return ((size_t)(i >> 3) * B + b) * 8 + (i & 7); }
 
 // workspace layout (floats): [slab MAX_BLOCKS x SLAB][z B x 2F][h B x H][dh B x H][dl B x KMAX]
 //                            [attention: aslab MAX_BLOCKS x 4EF — per-workgroup gradients of Wq, Wk, Wv, Wo]
