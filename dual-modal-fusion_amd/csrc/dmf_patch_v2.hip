@@ -493,11 +493,40 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const int32_t* xy_
   // pieces [k0, k1) of this wave's share
   auto issue_gather = [&](int x, int y, int k0, int k1) {
     const float* base = a.in.sceneA + ((size_t)x * a.in.Wp + y) * V::CW;     // (32-bit words: HF scenes hold two bands in each)
-    const int rowskip = (a.in.Wp - P) * V::CW;               // words between the end of a window row and the start of the next
     int l_ = lane;
     OPAQUE(l_);                                              // offsets are formed here, per patch: hoisted out of the patch loop
                                                              // they are spilled, and a scratch reload in front of a piece
                                                              // waits for every piece issued before it
+    if constexpr (V::CS == V::CW && V::RS == P * V::CW && V::RS >= 256 && V::RS % 4 == 0) {
+      // An image without any padding whose rows hold at least one piece (256 words): a piece lies in image row pr0 = 256 p / RS
+      // up to lane lb and in row pr0 + 1 from there on, and a lane's scene offset is its image offset + row * D (D = scene row
+      // stride - RS).  So everything per piece is SCALAR (row, boundary lane, the piece's base offset, which goes into the
+      // instruction's scalar offset); per lane it is a compare, a select and a shift-add.  (Formed per lane with integer
+      // divisions this was 12 vector instructions per piece, one of them a 64-bit multiply-add — 11 pieces per wave and
+      // patch, inside the two phases where the vector issue ports are the bound.)  Every lane of a piece is inside the
+      // image except in the last piece.
+      const int D4 = (a.in.Wp * V::CW - V::RS) * 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+      int w_ = wave;
+      asm volatile("" : "+s"(w_));                           // (formed here, per call: hoisted, 11 pieces' scalars are spilled)
+#pragma unroll
+      for (int k = 0; k < V::NK; ++k) {
+        if (k < k0 || k >= k1) continue;
+        const int p = w_ + k * V::NW;
+        if (p >= V::NPIECE) continue;                        // (scalar: this wave has no k-th piece)
+        const int n0 = p << 8;
+        const int pr0 = n0 / V::RS;
+        const int lb = (V::RS - (n0 - pr0 * V::RS)) >> 2;    // first lane of image row pr0 + 1 (>= 64: the piece stays in row pr0)
+        const int voff = (l_ << 4) + (l_ >= lb ? D4 : 0);
+        auto lds = (__attribute__((address_space(3))) void*)(smem + V::oX + p * 256);
+        if (p < V::NPIECE - 1 || 4 * l_ < P * V::RS - 256 * (V::NPIECE - 1))      // (a scalar branch around the last piece: no gain)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voff, 4 * n0 + D4 * pr0, 0, 0);
+      }
+#endif
+      return;
+    }
+    const int rowskip = (a.in.Wp - P) * V::CW;               // words between the end of a window row and the start of the next
 #pragma unroll
     for (int k = 0; k < V::NK; ++k) {
       if (k < k0 || k >= k1) continue;
