@@ -42,6 +42,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dmf_kargs.h"
 #include "dmf_lanes.h"
 
@@ -548,20 +550,6 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const int32_t* xy_
     }
   };
 
-  // The aux patch image [P][AR0] by LDS-DMA, 64 floats per piece, piece q by wave q % NW — IN FRONT of that wave's window
-  // pieces: requests of one CU are served in issue order, an aux row queued behind 100 KB of window would arrive with it.
-  auto issue_aux = [&](int x, int y) {
-    const float* base = a.in.sceneB + ((size_t)x * a.in.WpB + y) * C2;
-    int l_ = lane;
-    OPAQUE(l_);
-#pragma unroll
-    for (int q = 0; q < V::NAUXP; ++q) {
-      if (q % V::NW != wave) continue;
-      const int t = q * 64 + l_;
-      const int pr = t / V::AR0P, within = t - pr * V::AR0P;
-      dma_piece<4>(base, 0, (pr < P && within < V::AR0) ? (pr * a.in.WpB * C2 + within) * 4 : -1, smem + V::oAux + q * 64);
-    }
-  };
   // S > 1: the whole aux patch image, 1-KiB pieces; lane l of piece q holds image floats n = 256 q + 4 l .. + 3 = row n / RL,
   // PHYSICAL chunk (n % RL) / 4 = logical chunk rotated by the patch row (see V2::RL)
   auto issue_aux_s = [&](int x, int y) {
@@ -583,12 +571,14 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const int32_t* xy_
   // Wait until only this wave's window pieces are in flight, i.e. until everything it issued BEFORE them has landed: its
   // table-staging pieces (first patch) and its aux piece.  (vmcnt counts in issue order; the operand is an immediate, and a
   // wave issues NK pieces or — its last piece index beyond the image — NK - 1.)
-  auto wait_older_than_gather = [&]() {
+  // EXTRA: vector-memory operations this wave issued between what is waited for and its window pieces (the aux row's loads)
+  auto wait_older_than_gather = [&](auto extra) {
+    constexpr int EXTRA = decltype(extra)::value;
     if constexpr (V::K0 < V::NK) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::K0) : "memory");       // (pieces k < K0 <= NK - 1 exist for every wave)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::K0 + EXTRA) : "memory");       // (pieces k < K0 <= NK - 1 exist for every wave)
     } else {
-      if (wave + (V::NK - 1) * V::NW < V::NPIECE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK - 1) : "memory");
+      if (wave + (V::NK - 1) * V::NW < V::NPIECE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK + EXTRA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V::NK - 1 + EXTRA) : "memory");
     }
   };
 
@@ -718,7 +708,6 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
     float* sl = sSlab + qd * Sh::SLAB;                                             \
     (void)lead; (void)lim; (void)xr; (void)sl; (void)qd; (void)act
     VSTAMP(1);
-
     int it = 0;
     for (int b = blockIdx.x; b < B; b += gridDim.x, ++it) {
       // ------------------------------------------------------------------ aux row -> registers, window -> LDS
@@ -755,26 +744,12 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
           __builtin_amdgcn_sched_barrier(0);
           VSTAMP(11);
           __syncthreads();
-        } else if (it == 0) {
-          // first patch: the coordinates are all the gather needs — aux piece, then the first window pieces, go out BEFORE
-          // the wait for the staged tables; barrier X: every wave's staging pieces and aux piece have landed
-          issue_aux(x, y);
-          issue_gather(x, y, 0, V::K0);
-          __builtin_amdgcn_sched_barrier(0);
-          VSTAMP(11);
-          wait_older_than_gather();
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          // this lane's aux row, by reads the compiler cannot order behind the window pieces (hidden_read)
-          const unsigned aAux = lds_addr(smem + V::oAux) + 4u * (unsigned)(rc * V::AR0P);
-#pragma unroll
-          for (int j = 0; j < NV4; ++j) axv[j] = hidden_read4(aAux, j * 16);
-#pragma unroll
-          for (int i = 0; i < NR1; ++i) axt[i] = hidden_read(aAux, (4 * NV4 + i) * 4);
         } else {
-          // later patches: nothing to wait for and no barrier (the conv waves start without waiting for the head wave's
-          // tail) — the lane's aux row straight into registers, ahead of the window pieces in the memory pipeline.  Inline
-          // asm like the reads above: loads the compiler knows of would make it wait for them (and for every piece behind
-          // them) before the other path's asm may write the same registers.
+          // the lane's aux row straight into registers, ahead of the window pieces in the memory pipeline (every patch; the
+          // first patch used to fetch an aux IMAGE by LDS-DMA and read rows out of LDS behind barrier X).  Inline asm: loads
+          // the compiler knows of would make it wait for them (and for every piece behind them) at the next LDS access it
+          // can see.  Their results are pinned behind the wait (HIDDEN_USE): an asm output nobody reads gets a register the
+          // compiler reuses at once, and the result landing late would overwrite whatever lives there by then.
           const float* srcB = a.in.sceneB + ((size_t)(x + rc) * a.in.WpB + y) * C2;
 #pragma unroll
           for (int j = 0; j < NV4; ++j) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(axv[j]) : "v"(srcB), "n"(16 * j) : "memory");
@@ -782,6 +757,14 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
           for (int i = 0; i < NR1; ++i) asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(axt[i]) : "v"(srcB), "n"(4 * (4 * NV4 + i)) : "memory");
           issue_gather(x, y, 0, V::K0);
           __builtin_amdgcn_sched_barrier(0);
+          if (it == 0) {
+            // barrier X: the staged tables (theta, pooling profile: LDS-DMA of ALL waves) are complete.  A wave waits for ITS
+            // staging pieces only — everything it issued before the aux row loads and the window pieces above; it used to
+            // wait here for an LDS-DMA aux image too, which depends on the coordinates: the barrier stood at ~3.4 K cycles.
+            VSTAMP(11);
+            wait_older_than_gather(std::integral_constant<int, NV4 + NR1>());
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
         }
         {   // the next patch's coordinates, a whole patch ahead of their use
           const int bn = b + (int)gridDim.x < B ? b + (int)gridDim.x : b;
@@ -837,7 +820,7 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
           for (int c = 0; c < P; ++c) { const float4 v = ddbv[c / 4]; pw[c] = (c & 3) == 0 ? v.x : (c & 3) == 1 ? v.y : (c & 3) == 2 ? v.z : v.w; }
         }
         if constexpr (INMODE == 1 && !V::SX) {
-          wait_older_than_gather();      // later patches: the aux row's loads (first patch: already waited for in front of barrier X)
+          wait_older_than_gather(std::integral_constant<int, 0>());      // the aux row's loads
 #pragma unroll
           for (int j = 0; j < NV4; ++j) {
             HIDDEN_USE(axv[j]);
@@ -1138,14 +1121,13 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
         const int x = xn, y = yn;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (V::SX) issue_aux_s(x, y);
-        else if (it == 0) issue_aux(x, y);
         issue_gather(x, y, 0, V::K0);                    // this wave's share of the window: the first pieces ...
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (V::SX) {
           __syncthreads();                               // (every patch: the aux image is complete, see the conv waves)
         } else if (it == 0) {
-          wait_older_than_gather();
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // barrier X (first patch)
+          wait_older_than_gather(std::integral_constant<int, 0>());
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // barrier X (first patch): staged tables complete
         }
         issue_gather(x, y, V::K0, V::NK);                // ... and the rest (nothing else to do until barrier 1)
         __builtin_amdgcn_sched_barrier(0);
