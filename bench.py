@@ -148,6 +148,24 @@ def exchange_matches_rccl(eng, comm, pg, step, backend):
     return True
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run as a CHILD
+    process (this process has not initialised the GPU and never will), pass its output through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: what RCCL and the exchange's HIP-IPC mapping need here
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,6 +183,7 @@ def main():
     ap.add_argument('--kappa-steps', type=int, default=2200, help='train to this many steps (from the initial weights) before kappa')
     ap.add_argument('--cpu-seconds', type=float, default=90.0, help='CPU oracle budget (rank 0, N=1 only)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-cpu-spread', action='store_true', help='skip the second CPU oracle training (kappa noise floor)')
     args = ap.parse_args()
     for k, v in CONFIGS[args.config].items():
         if k != 'name' and getattr(args, k) is None:
@@ -178,9 +197,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d'
-                             % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and 'RANK' not in os.environ:
+            return spawn_ranks(args.gpus)           # `python bench.py --gpus N` starts its own N ranks (nothing has touched the GPU yet)
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
@@ -200,9 +218,7 @@ def main():
             dist.init_process_group(backend)
         pg = dist.group.WORLD
     if args.config == '4':
-        if world > 1:
-            raise SystemExit('--config 4 (stage 2) runs on one GPU')
-        return main_stage2(args, dev)
+        return main_stage2(args, dev, pg, rank, world, backend)
 
     from dmf import lib
     from dmf.engine import EvalEngine, LossScaler, Scene, TrainEngine
@@ -293,6 +309,12 @@ def main():
     if comm is not None:
         if vote_bad(comm.status() != 0):        # every rank leaves together
             raise SystemExit('rank %d: a gradient exchange timed out waiting for a peer — the timing is void' % rank)
+    n_ranks_seen = 1
+    if world > 1:                               # how many ranks the process group really has: a sum of ones
+        import torch.distributed as dist
+        one = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(one)
+        n_ranks_seen = int(one.item())
     value = world * B * K_steps / dt
 
     # ---- instrumented pass: mean duration of the dominant kernel, HIP events on the launch stream
@@ -375,12 +397,13 @@ def main():
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': ('f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32')
                  if not args.attention else 'f32 (attention operands bf16, f32 accumulate)', 'data': 'synthetic',
-        'config': {'workload': '%s; %dx%d patches, %d logits, batch %d per GPU, fused HIP fwd+loss+bwd+Adam'
-                               % (CONFIGS[args.config]['name'], P, P, args.classes + 1, B),
+        'config': {'workload': '%s; %dx%d scene, %d + %d bands, %dx%d patches, %d logits, batch %d per GPU, fused HIP fwd+loss+bwd+Adam'
+                               % (CONFIGS[args.config]['name'], args.size, args.size, C, C2, P, P, args.classes + 1, B),
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch,
                    'device_prewarm_ms': round(prewarm_ms, 1), 'graph_warm_replay': bool(graph_warmed),
                    'allreduce': 'none' if world == 1 else ('xgmi one-shot, fused in the reduce+Adam launch' if comm is not None
-                                                           else 'rccl all_reduce of one flat fp32 gradient')},
+                                                           else '%s all_reduce of one flat fp32 gradient' % ('rccl' if backend == 'nccl' else backend)),
+                   'n_ranks_seen': n_ranks_seen},
         'roofline': roof,
         'step_frac_of_hbm_roof': value / world * (alg_patch + 28.0 * eng.theta.numel() / B) / HBM_PEAK,
     }
@@ -449,15 +472,38 @@ def main():
                                  'cpu_after_parity_steps': k_cpu, 'gpu_after_parity_steps': k_gpu,
                                  'abs_delta_kappa': abs(k_cpu - k_gpu), 'within_0.001': bool(abs(k_cpu - k_gpu) <= 1e-3),
                                  'confusion_entries_differing': int(np.abs(m_cpu - m_gpu).sum() // 2)})
+            # the noise floor that delta is to be read against, measured in THIS run: the same CPU oracle, same initial weights,
+            # same batches, same test patches, only the thread count (= the partition of its fp32 reductions) changed
+            if not args.no_cpu_spread:
+                n_thr2 = n_thr - 3 if n_thr >= 6 else n_thr + 1
+                torch.set_num_threads(n_thr2)
+                ref2 = RefNet(cfg)
+                ref2.load_state_dict(init_state)
+                opt2 = torch.optim.Adam(ref2.parameters(), lr=1e-3)
+                t2 = time.perf_counter()
+                for c0 in range(0, n_k, chunk):
+                    n_c = min(chunk, n_k - c0)
+                    sl = mine[c0 * B:(c0 + n_c) * B]
+                    _, opt2 = solver_ref.train_steps(ref2, MS, PAN, xy_tab[sl], lab_tab[sl], B, P, S, optimizer=opt2)
+                m_cpu2, _ = solver_ref.evaluate(ref2, MS, PAN, xy_tab[test[:n_kt]], lab_tab[test[:n_kt]], args.classes + 1, P, S)
+                k_cpu2 = aa_oa_quiet(m_cpu2)[2]
+                spread = abs(k_cpu - k_cpu2)
+                out['kappa'].update({'cpu_second_run_threads': n_thr2, 'cpu_second_run_kappa': k_cpu2, 'cpu_kappa_spread': spread,
+                                     'cpu_vs_cpu_confusion_entries_differing': int(np.abs(m_cpu - m_cpu2).sum() // 2),
+                                     'within_cpu_spread': bool(abs(k_cpu - k_gpu) <= spread),
+                                     'cpu_second_run_seconds': round(time.perf_counter() - t2, 1)})
+                torch.set_num_threads(n_thr)
     print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
 
 
-def main_stage2(args, dev):
+def main_stage2(args, dev, pg=None, rank=0, world=1, backend='nccl'):
     """--config 4: the stage-2 step of the two-stage path (solver/tostagesolver.py:259-315): four stacked streams through the
-    one-input net, qua_loss, backward, ADAM.  A step processes 4*bs stacked patches; `value` counts those."""
+    one-input net, qua_loss, backward, ADAM.  A step processes 4*bs stacked patches per GPU; `value` counts those.
+    N ranks: every rank takes bs pixels of each global batch of N*bs, the logits are gathered so that the batch-coupled loss is
+    the global batch's, the flat gradient is all-reduced (dmf.engine.QuaTrainEngine); eager launches, no loss scaler."""
     from dmf import lib, synth
     from dmf.engine import LossScaler, QuaScene, QuaTrainEngine
     from function.function import data_padding
@@ -475,13 +521,13 @@ def main_stage2(args, dev):
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     scene = QuaScene(scenes, dev, half=bool(args.half))
-    sc = LossScaler(dev) if args.half else None        # GradScaler's defaults (tostagesolver.py:83-84)
-    eng = QuaTrainEngine(net, scene, bs, cfg['dqtl'], lr=1e-3, scaler=sc)
+    sc = LossScaler(dev) if (args.half and world == 1) else None        # GradScaler's defaults (tostagesolver.py:83-84)
+    eng = QuaTrainEngine(net, scene, bs, cfg['dqtl'], lr=1e-3, scaler=sc, process_group=pg)
     total = W_steps + K_steps
-    xy = np.stack([g.integers(0, H, total * bs), g.integers(0, W, total * bs)], 1).astype(np.int32)
+    xy = np.stack([g.integers(0, H, total * bs * world), g.integers(0, W, total * bs * world)], 1).astype(np.int32)
     lab = np.maximum(label[xy[:, 0], xy[:, 1]], 1).astype(np.int32)
-    eng.load_plan(xy, lab)
-    spg = min(args.steps_per_graph, K_steps) if eng.unit else 0
+    eng.load_plan(xy, lab)                                 # global batches; the engine keeps this rank's rows
+    spg = min(args.steps_per_graph, K_steps) if (eng.unit and world == 1) else 0
     # device warm-up that touches no training state (see prewarm()): the eval forward of the first stacked batch, ~60 ms
     inp0 = lib.input_gather(eng.shape, scene.A, scene.B, eng.plan_xy[:4 * bs])
     lg0 = torch.empty_like(eng.logits)
@@ -494,15 +540,36 @@ def main_stage2(args, dev):
     launch, n_replays = launch_label(spg, K_steps)
     if n_replays and eng.graph is None:
         eng._capture(spg)
-    torch.cuda.synchronize()
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     if n_replays:
         eng.run_plan(K_steps, spg)
     else:
         eng.run_plan(K_steps)
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    n_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        one = torch.ones(1, device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(one)
+        n_seen = int(one.item())
     losses = eng.losses().numpy()
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     P = args.patch
     alg_patch = 2 * ((2 if args.half else 4) * P * P * 4 + 4 * P * P * 1)
     # dominant kernel: the forward(+unit-gradient) patch kernel over the 4*bs stacked patches, HIP events on the launch stream
@@ -518,13 +585,15 @@ def main_stage2(args, dev):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[n_inst // 10:]]))
     out = {
         'metric': 'training patches/sec + kappa, 11x11x200 HSI + 11x11x1 SAR, 1/2/4/8 MI355X',
-        'value': 4 * bs * K_steps / dt, 'unit': 'patches/s', 'n_gpus': 1, 'steps': K_steps, 'warmup': W_steps,
+        'value': world * 4 * bs * K_steps / dt, 'unit': 'patches/s', 'n_gpus': world, 'steps': K_steps, 'warmup': W_steps,
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32',
         'data': 'synthetic',
         'config': {'workload': '%s; %dx%d patches, %d logits, bs %d (%d stacked patches per step), qua_loss, fused HIP step'
                                % (CONFIGS['4']['name'], P, P, args.classes + 1, bs, 4 * bs),
-                   'global_batch': 4 * bs, 'parallelism': 'dp1', 'launch': launch, 'allreduce': 'none'},
+                   'global_batch': 4 * bs * world, 'parallelism': 'dp%d' % world, 'launch': launch,
+                   'allreduce': 'none' if world == 1 else '%s all_gather of the logits + all_reduce of one flat fp32 gradient per step' % backend,
+                   'n_ranks_seen': n_seen},
         'roofline': {'bound': 'hbm', 'achieved': 4 * bs * alg_patch / (kern_ms * 1e-3) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': 4 * bs * alg_patch / (kern_ms * 1e-3) / HBM_PEAK, 'traffic': None,
                      'kernel': eng.dominant_name(), 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': 4 * bs * alg_patch},
@@ -532,7 +601,7 @@ def main_stage2(args, dev):
     }
     if sc is not None:
         out['loss_scaler'] = {'scale': sc.get_scale(), 'skipped_steps': sc.skipped_steps()}
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:
         from oracle.gmfnet_ref import Net as RefNet
         from oracle import solver_ref
         torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
@@ -554,6 +623,10 @@ def main_stage2(args, dev):
                                'sample': '%d stage-2 steps (bs %d) after a warm-up chunk, oracle/solver_ref.py::qua_train_steps, %.1f s timed'
                                          % (n_t, bs, t_t)}
     print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

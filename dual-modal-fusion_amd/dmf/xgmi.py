@@ -69,8 +69,16 @@ def _all_agree(ok, group, device):
     return bool(t.item())
 
 
+ADMISSION_ROUNDS = 6
+
+
 def create(capacity, group=None, timeout_ms=20000, verbose=True):
-    """Build a communicator and prove it with two known-answer exchanges; None (on every rank) if that fails."""
+    """Build a communicator and prove it before it is handed out; None (on every rank) if that fails.
+
+    The proof is ADMISSION_ROUNDS exchanges whose lengths change from round to round: every parity slot of the inbox is
+    REUSED at least twice (round 1's wrong 3-rank sums appeared exactly at the first reuse, in the third exchange — two rounds
+    would never have seen them), on seeded random data as well as on a known-answer pattern, each compared bit for bit with
+    the rank-ordered sum formed from the group's own all_gather.  Any mismatch or time-out on any rank fails all ranks."""
     backend = dist.get_backend(group)
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
     comm, err = None, ''
@@ -81,15 +89,28 @@ def create(capacity, group=None, timeout_ms=20000, verbose=True):
     ok = _all_agree(comm is not None, group, dev)
     if ok:
         world, rank = comm.world, comm.rank
-        n = min(comm.capacity, 4096)
-        for rnd in range(2):                    # two rounds: both parities of the publish buffer
-            buf = (torch.arange(n, dtype=torch.float32, device='cuda') % 97) * (rank + 1) + rnd
-            want = (torch.arange(n, dtype=torch.float32, device='cuda') % 97) * (world * (world + 1) // 2) + rnd * world
+        cap = comm.capacity
+        for rnd in range(ADMISSION_ROUNDS):
+            n = max(1, min(cap, cap - (rnd * 977) % max(cap // 2, 1)))      # full length first, then shorter and changing
+            if rnd % 2 == 0:                    # known answer
+                mine = (torch.arange(n, dtype=torch.float32, device='cuda') % 97) * (rank + 1) + rnd
+            else:                               # seeded random data, different on every rank
+                gen = torch.Generator(device='cuda').manual_seed(1000 * rnd + rank)
+                mine = torch.randn(n, device='cuda', generator=gen)
+            parts = [torch.empty(n, device=dev) for _ in range(world)]
+            dist.all_gather(parts, mine.to(dev), group=group)
+            want = parts[0].to('cuda').clone()
+            for r in range(1, world):
+                want += parts[r].to('cuda')     # rank order, like the kernel
+            buf = mine.clone()
             comm.allreduce_(buf)
             good = comm.status() == 0 and torch.equal(buf, want)
             ok = _all_agree(good, group, dev) and ok
             if not good:
-                err = err or 'known-answer exchange failed (status %d)' % comm.status()
+                err = err or 'admission exchange %d of %d failed (status %d, %d of %d elements differ)' % (
+                    rnd + 1, ADMISSION_ROUNDS, comm.status(), int((buf != want).sum()), n)
+            if not ok:
+                break
         comm.c.timeout_ms = int(timeout_ms)
     if not ok:
         if comm is not None:

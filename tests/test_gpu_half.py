@@ -335,12 +335,19 @@ def test_engine_with_the_references_other_optimizers(kind, graph):
 
 @pytest.mark.parametrize('kind', ['SGD', 'RMSprop'])
 def test_stage2_engine_with_the_references_other_optimizers(kind):
-    """Stage 2 (qua_loss, unit-gradient step from a captured graph) under SGD / RMSprop against the oracle's loop
-    (oracle/solver_ref.py::qua_train_steps) driven by torch's optimiser."""
+    """Stage 2 (qua_loss, unit-gradient step) under SGD / RMSprop against the oracle's loop (oracle/solver_ref.py::
+    qua_train_steps) driven by torch's optimiser.
+
+    Two parts.  (1) Free running from a captured graph: the per-step losses follow the oracle.  (2) Step by step from the
+    ORACLE's state (weights and optimiser state are copied into the engine before every step): the update of every element
+    whose gradient stands clear of rounding noise agrees tightly, the others are bounded by what the optimiser can make of a
+    noise-level gradient.  A free-running comparison of the weights proves nothing here: RMSprop turns a gradient of 1e-8
+    into a step of ~lr, and the CPU oracle against ITSELF at 1 / 16 threads (a different partition of its reductions) is
+    2.2e-3 apart after three of these steps (tools/diag_rms.py) — the same size as its distance to the GPU."""
     from dmf.engine import QuaScene, QuaTrainEngine
     from oracle.solver_ref import qua_train_steps
     from oracle.gmfnet_ref import Net as RefNet
-    from model.gmfnet import Net as HipNet
+    from model.gmfnet import Net as HipNet, PARAM_ORDER
     C, C2, P, S, K = SHAPES['qua']
     cfg = make_cfg('qua')
     cfg['gmf']['single_input'] = 1
@@ -353,24 +360,49 @@ def test_stage2_engine_with_the_references_other_optimizers(kind):
     scenes = [(torch.rand(H + P - 1, W + P - 1, C, generator=g) - 0.2).numpy() for _ in range(4)]
     xy = torch.stack([torch.randint(0, H, (n * bs,), generator=g), torch.randint(0, W, (n * bs,), generator=g)], 1).int()
     lab = torch.randint(0, K, (n * bs,), generator=g)
+    lr = 0.05 if kind == 'SGD' else 2e-3
     if kind == 'SGD':
-        opt, kw = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9), dict(optimizer='SGD', lr=0.05, momentum=0.9)
+        opt, kw = torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9), dict(optimizer='SGD', lr=lr, momentum=0.9)
     else:
-        opt, kw = torch.optim.RMSprop(ref.parameters(), lr=2e-3, alpha=0.9), dict(optimizer='RMSprop', lr=2e-3, alpha=0.9)
-    want, _ = qua_train_steps(ref, scenes, xy.numpy(), lab.numpy(), bs, P, dqtl, optimizer=opt)
-    eng = QuaTrainEngine(hip, QuaScene(scenes, 'cuda:0'), bs, dqtl, **kw)
-    eng.load_plan(xy, lab)
-    eng.run_plan(n, steps_per_graph=3)
-    assert np.allclose(eng.losses().numpy(), want, atol=2e-5, rtol=1e-5), (eng.losses().numpy(), want)
-    sd = ref.state_dict()
-    for k, v in hip.state_dict().items():
-        if kind == 'RMSprop':
-            # RMSprop divides by sqrt(mean g^2) + 1e-8: an element whose gradient is rounding noise (|g| ~ eps) moves by up to lr per
-            # step whatever its size, like ADAM's dead channels — nearly all within tolerance, all within n lr
-            err = (v.cpu() - sd[k]).abs()
-            assert (err > 1e-4 + 2e-4 * sd[k].abs()).float().mean() < 0.03 and err.max() < n * 2e-3, (k, err.max())
-        else:
-            assert_close(v, sd[k], 1e-4, 2e-4, 'stage-2 %s: param %s' % (kind, k))
+        opt, kw = torch.optim.RMSprop(ref.parameters(), lr=lr, alpha=0.9), dict(optimizer='RMSprop', lr=lr, alpha=0.9)
+    qscene = QuaScene(scenes, 'cuda:0')
+    eng = QuaTrainEngine(hip, qscene, bs, dqtl, **kw)
+    off = hip._offsets
+    named = dict(ref.named_parameters())
+    key = 'momentum_buffer' if kind == 'SGD' else 'square_avg'
+    want = []
+    for i in range(n):
+        # the oracle's state BEFORE step i -> the engine
+        hip.load_state_dict(ref.state_dict())
+        eng.theta = hip.flat_parameters()
+        for j, k in enumerate(PARAM_ORDER):
+            st = opt.state.get(named[k], {})
+            eng.m[off[j]:off[j] + named[k].numel()] = (st[key].reshape(-1) if key in st else torch.zeros(named[k].numel())).cuda()
+        eng.step_count = i
+        eng.dev_step.fill_(i)
+        before = {k: v.detach().clone() for k, v in named.items()}
+        l, _ = qua_train_steps(ref, scenes, xy.numpy(), lab.numpy(), bs, P, dqtl, optimizer=opt, batches=[np.arange(i * bs, (i + 1) * bs)])
+        want += l
+        eng.step(xy[i * bs:(i + 1) * bs], lab[i * bs:(i + 1) * bs])
+        assert abs(float(eng.loss.item()) - l[0]) < 2e-5, (i, float(eng.loss.item()), l[0])
+        got = dict(hip.named_parameters())
+        for k, p_ in named.items():
+            gr = p_.grad.detach().abs()
+            solid = gr > 1e-3 * gr.max().clamp_min(1e-30)
+            d_ref, d_got = p_.detach() - before[k], got[k].detach().cpu() - before[k]
+            err = (d_got - d_ref).abs()
+            assert (err[solid] <= 5e-6 + 5e-3 * d_ref.abs()[solid]).all(), (kind, i, k, float(err[solid].max()))   # (updates are ~lr .. 3 lr)
+            assert float(err.max()) <= 3.3 * lr, (kind, i, k, float(err.max()))       # a noise-level gradient: at most ~3.2 lr
+    # free running, from a captured graph: the losses of the first steps (before the weights can have drifted apart)
+    torch.manual_seed(5)
+    ref2 = RefNet(cfg)
+    hip2 = HipNet(cfg); hip2.load_state_dict(ref2.state_dict()); hip2 = hip2.cuda()
+    eng2 = QuaTrainEngine(hip2, qscene, bs, dqtl, **kw)
+    eng2.load_plan(xy, lab)
+    eng2.run_plan(n, steps_per_graph=3)
+    opt2 = (torch.optim.SGD(ref2.parameters(), lr=lr, momentum=0.9) if kind == 'SGD' else torch.optim.RMSprop(ref2.parameters(), lr=lr, alpha=0.9))
+    want2, _ = qua_train_steps(ref2, scenes, xy.numpy(), lab.numpy(), bs, P, dqtl, optimizer=opt2)
+    assert np.allclose(eng2.losses().numpy(), want2, atol=1e-4, rtol=1e-4), (eng2.losses().numpy(), want2)
 
 
 @pytest.mark.parametrize('half', [False, True])
