@@ -148,6 +148,34 @@ def exchange_matches_rccl(eng, comm, pg, step, backend):
     return True
 
 
+VALU_CYCLES_PER_INSTR = 3.15     # best measured vector-issue interval of one SIMD (profiles/r2_valu_rate.txt: v_fmac_f32, 4 waves per SIMD)
+SHADER_CLOCK = 2.4e9             # Hz, MI355X maximum (MI355X_MICROARCH.md)
+
+
+def issue_roofline(cfgname, kernel_key, kern_ms):
+    """Vector-issue roofline of the dominant kernel: the vector instructions one launch issues (SQ_INSTS_VALU, collected by
+    tools/collect_r3.sh into profiles/issue_counts.json for the default shape of --config 1 / 4 / panms) / its measured duration,
+    against 1024 SIMDs x clock / the best measured issue interval.  For a 4-KB patch the HBM roof says nothing (frac 0.02):
+    these kernels issue ~12-17 K vector instructions per patch whatever the number of bands."""
+    path = os.path.join(ROOT, 'profiles', 'issue_counts.json')
+    if kern_ms is None or not os.path.exists(path):
+        return None
+    try:
+        kern = json.load(open(path))['configs'].get(cfgname, {})
+    except Exception:
+        return None
+    hit = [v for k, v in kern.items() if kernel_key in k and 'SQ_INSTS_VALU' in v]
+    if not hit:
+        return None
+    n_valu, n_salu = hit[0]['SQ_INSTS_VALU'], hit[0].get('SQ_INSTS_SALU')
+    peak = 1024 * SHADER_CLOCK / VALU_CYCLES_PER_INSTR
+    ach = n_valu / (kern_ms * 1e-3)
+    return {'bound': 'vector issue', 'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instructions/s', 'frac': ach / peak,
+            'valu_instructions_per_launch': n_valu, 'salu_instructions_per_launch': n_salu,
+            'basis': 'SQ_INSTS_VALU per launch (profiles/issue_counts.json, default shape of this --config) / kernel_ms; peak = 1024 SIMDs x '
+                     '2.4 GHz / 3.15 cycles per instruction (profiles/r2_valu_rate.txt)'}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run as a CHILD
     process (this process has not initialised the GPU and never will), pass its output through, return its exit code."""
@@ -248,7 +276,7 @@ def main():
     mine = plan_idx.reshape(plan_steps, world, B)[:, rank, :].reshape(-1)      # this rank's contiguous shard per step
     eng.load_plan(xy_tab[mine], lab_tab[mine])
     prewarm_ms = prewarm(eng, net, args, 60.0)
-    graphable = world == 1 or comm is not None                                 # RCCL path: eager launches
+    graphable = eng._graphable()               # one GPU, the one-shot exchange, or RCCL's all-reduce captured with the step
     spg = min(args.steps_per_graph, K_steps) if graphable else 0
 
     def sync():
@@ -282,15 +310,23 @@ def main():
             net.load_state_dict(init_state)
             eng = TrainEngine(net, scene, B, lr=1e-3, process_group=pg, comm=None, scaler=scaler())
             eng.load_plan(xy_tab[mine], lab_tab[mine])
-            spg = 0
-            eng.run_plan(W_steps, 0)
+            spg = min(args.steps_per_graph, K_steps) if eng._graphable() else 0
+            eng.run_plan(W_steps, spg)
     else:
         # the warm-up runs through the SAME captured graph as the timed steps (whole graphs, the rest eagerly): the first
         # replay of a graph pays its one-time upload, which belongs to the warm-up
         eng.run_plan(W_steps, spg)
     launch, n_replays = launch_label(spg, K_steps)
     if n_replays and eng.graph is None:
-        eng._capture(spg)                       # capture restores state: no steps are consumed
+        try:
+            eng._capture(spg)                   # capture restores state: no steps are consumed
+        except RuntimeError:
+            if world == 1 or comm is not None:
+                raise
+            eng._rccl_graph, eng.graph, spg = False, None, 0       # RCCL refused the capture: eager steps (see TrainEngine.run_plan)
+            launch, n_replays = launch_label(0, K_steps)
+    if n_replays and eng.graph is None:
+        launch, n_replays = launch_label(0, K_steps)
     graph_warmed = False
     if n_replays and W_steps < spg:
         # the warm-up was shorter than one graph, so the graph executable has never been launched: one replay whose effects
@@ -402,11 +438,17 @@ def main():
                    'global_batch': B * world, 'parallelism': 'dp%d' % world, 'launch': launch,
                    'device_prewarm_ms': round(prewarm_ms, 1), 'graph_warm_replay': bool(graph_warmed),
                    'allreduce': 'none' if world == 1 else ('xgmi one-shot, fused in the reduce+Adam launch' if comm is not None
-                                                           else '%s all_reduce of one flat fp32 gradient' % ('rccl' if backend == 'nccl' else backend)),
+                                                           else '%s all_reduce of one flat fp32 gradient%s' % ('rccl' if backend == 'nccl' else backend,
+                                                                                                                      ', captured in the step graph' if n_replays else ', host-enqueued')),
                    'n_ranks_seen': n_ranks_seen},
         'roofline': roof,
         'step_frac_of_hbm_roof': value / world * (alg_patch + 28.0 * eng.theta.numel() / B) / HBM_PEAK,
     }
+    default_shape = all(getattr(args, k) == v for k, v in CONFIGS[args.config].items() if k != 'name')
+    if not args.attention and not args.half and default_shape:
+        ir = issue_roofline(args.config if args.config != '3' else '', ', 1, 1, false>', kern_ms)
+        if ir is not None:
+            out['issue_roofline'] = ir
     if exchange_note:
         out['config']['allreduce_note'] = exchange_note
     if losses.size:
@@ -490,6 +532,9 @@ def main():
                 spread = abs(k_cpu - k_cpu2)
                 out['kappa'].update({'cpu_second_run_threads': n_thr2, 'cpu_second_run_kappa': k_cpu2, 'cpu_kappa_spread': spread,
                                      'cpu_vs_cpu_confusion_entries_differing': int(np.abs(m_cpu - m_cpu2).sum() // 2),
+                                     'abs_delta_kappa_vs_second_cpu_run': abs(k_cpu2 - k_gpu),
+                                     # is the GPU run as close to a CPU run as the CPU runs are to each other?
+                                     'gpu_within_cpu_run_to_run_spread': bool(min(abs(k_cpu - k_gpu), abs(k_cpu2 - k_gpu)) <= spread),
                                      'within_cpu_spread': bool(abs(k_cpu - k_gpu) <= spread),
                                      'cpu_second_run_seconds': round(time.perf_counter() - t2, 1)})
                 torch.set_num_threads(n_thr)
@@ -599,6 +644,10 @@ def main_stage2(args, dev, pg=None, rank=0, world=1, backend='nccl'):
                      'kernel': eng.dominant_name(), 'kernel_ms': kern_ms, 'algorithmic_bytes_per_launch': 4 * bs * alg_patch},
         'loss_first_last': [float(losses[0]), float(losses[-1])] if losses.size else None,
     }
+    if world == 1 and all(getattr(args, k) == v for k, v in CONFIGS['4'].items() if k != 'name') and eng.unit:
+        ir = issue_roofline('4', ', 5, 1, %s>' % ('true' if args.half else 'false'), kern_ms)
+        if ir is not None:
+            out['issue_roofline'] = ir
     if sc is not None:
         out['loss_scaler'] = {'scale': sc.get_scale(), 'skipped_steps': sc.skipped_steps()}
     if not args.no_cpu and world == 1:

@@ -444,7 +444,10 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const int32_t* xy_
   VSTAMP_W(0);
   // the head wave is the youngest wave of its SIMD: at equal priority it only gets the issue slots its two conv waves leave,
   // and every barrier then waits for it
-  if (wave == V::NB) __builtin_amdgcn_s_setprio(3);
+  // the head wave stays at priority 0 until barrier W: up to there it only issues its share of the gather, and at priority 3
+  // those ~300 scalar + vector instructions came out of the issue slots of the two conv waves of its SIMD, the waves every
+  // barrier of the prologue then waited for (16.16 -> 16.05 us per step).  Behind barrier W it is the youngest wave of its
+  // SIMD with the longest dependent chain (fc1 -> fc2 -> softmax -> dh): priority 3 from there.
   else if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
                                                           // wave of a SIMD wins every arbitration and the younger one trails it
   if constexpr (TOK) {   // token staging [2][128][TKS] halves behind the fixed regions: zero once (padding tokens / channels stay 0)
@@ -1146,6 +1149,7 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
       if (MODE == MODE_BWD) dlx = lane < K ? a.dlogits[(size_t)b * K + lane] : 0.f;
       __syncthreads();                                   // barrier W: window complete (this wave's pieces included)
       VSTAMP(4);
+      __builtin_amdgcn_s_setprio(3);
       if (it == 0 && !TOK && !DENSE) {   // head tables, behind the gather: nobody needs them before barrier 1, and 20 row-strided loads inside
                        // the gather stream would delay every wave's pieces (one memory pipeline per CU)
 #pragma unroll

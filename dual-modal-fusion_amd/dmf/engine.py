@@ -284,12 +284,21 @@ class TrainEngine:
             raise lib.DmfError('run_plan(%d): the loaded plan has %d steps, %d of them done' % (
                 steps, getattr(self, 'plan_steps', 0), self.host_cursor))
         done = 0
-        if steps_per_graph > 0 and (self.world == 1 or self.comm is not None):
+        if steps_per_graph > 0 and self._graphable():
             # lr, betas and eps are launch arguments baked into the captured graph (reference: `scheduler.step()` changes
             # the optimiser's lr every epoch, mainsolver.py:60): a change invalidates the graph
             if self.graph is None or self.graph_steps != steps_per_graph or self.graph_hparams != self._hparams():
-                self._capture(steps_per_graph)
-            while steps - done >= steps_per_graph:
+                try:
+                    self._capture(steps_per_graph)
+                except RuntimeError:
+                    if self.world == 1 or self.comm is not None:
+                        raise
+                    # RCCL's all-reduce refused to be captured (every rank runs the same software, so every rank lands
+                    # here): stay on eager launches for the rest of this engine's life
+                    self._rccl_graph = False
+                    self.graph = None
+                    torch.cuda.synchronize()
+            while self.graph is not None and steps - done >= steps_per_graph:
                 self._fill_window(steps_per_graph)
                 self.graph.replay()
                 self.step_count += steps_per_graph
@@ -298,6 +307,18 @@ class TrainEngine:
         for _ in range(steps - done):
             self._plan_step()
         return steps
+
+    def _graphable(self):
+        """Can a step be captured in a hipGraph?  One GPU: yes.  The one-shot exchange: yes (it is part of the reduce launch).
+        The RCCL all-reduce: yes when the process group is RCCL — its collectives are capturable, and a host-enqueued
+        all_reduce of 32 KB per ~16-us step would otherwise bound the step by the host (DMF_RCCL_GRAPH=0 switches this off)."""
+        if self.world == 1 or self.comm is not None:
+            return True
+        if self.scaler is not None or self.optim != 'ADAM' or not getattr(self, '_rccl_graph', True):
+            return False
+        import os
+        import torch.distributed as dist
+        return dist.get_backend(self.pg) == 'nccl' and os.environ.get('DMF_RCCL_GRAPH', '1') != '0'
 
     def _capture(self, n):
         # hipFuncSetAttribute is not capturable, so every kernel must have been launched once before the capture:

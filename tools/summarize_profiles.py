@@ -97,6 +97,32 @@ def main():
 
 
 
+def issue_counts(tag):
+    """gpurun_out/pmc_valu{1,4,pan}: SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVES of every dmf kernel (rocprofv3 --pmc ... on
+    bench.py --config 1 / 4 / panms, eager launches) -> profiles/<tag>_issue_counts.json + profiles/issue_counts.json (bench.py
+    reads the latter for its `issue_roofline`).  The counters are per launch, summed over all waves of the grid."""
+    res = {'round': tag, 'counters': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --kernel-trace', 'configs': {}}
+    for name, cfgname in (('pmc_valu1', '1'), ('pmc_valu4', '4'), ('pmc_valupan', 'panms')):
+        files = newest(glob.glob(os.path.join(ROOT, 'gpurun_out', name, '**', '*_counter_collection.csv'), recursive=True))
+        if not files:
+            continue
+        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(files[0])):
+            if 'dmf::' in r['Kernel_Name']:
+                d[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+        kern = {}
+        for k, c in d.items():
+            short = k.split('(')[0].replace('void ', '')
+            kern[short] = {n: statistics.median(v) for n, v in c.items()}
+            kern[short]['launches'] = len(next(iter(c.values())))
+        res['configs'][cfgname] = kern
+    json.dump(res, open(os.path.join(ROOT, 'profiles', tag + '_issue_counts.json'), 'w'), indent=1)
+    json.dump(res, open(os.path.join(ROOT, 'profiles', 'issue_counts.json'), 'w'), indent=1)
+    for cfgname, kern in res['configs'].items():
+        for k, v in kern.items():
+            print(cfgname, k[:90], {n: int(x) for n, x in v.items()})
+
+
 def configs_md(tag):
     """gpurun_out/<tag>_config_lines.jsonl (tools/collect_r2.sh: a '# command' line, then bench.py's JSON line) -> profiles/<tag>_configs.md"""
     src = os.path.join(ROOT, 'gpurun_out', tag + '_config_lines.jsonl')
@@ -125,3 +151,4 @@ def configs_md(tag):
 if __name__ == '__main__':
     main()
     configs_md(sys.argv[1] if len(sys.argv) > 1 else 'r1')
+    issue_counts(sys.argv[1] if len(sys.argv) > 1 else 'r1')
