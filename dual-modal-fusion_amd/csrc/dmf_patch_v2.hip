@@ -442,13 +442,11 @@ __global__ __launch_bounds__(V2<Sh>::NT) void patch_v2_kernel(const int32_t* xy_
   VSTAMP_DECL;
   VSTAMP_RT(12);
   VSTAMP_W(0);
-  // the head wave is the youngest wave of its SIMD: at equal priority it only gets the issue slots its two conv waves leave,
-  // and every barrier then waits for it
   // the head wave stays at priority 0 until barrier W: up to there it only issues its share of the gather, and at priority 3
   // those ~300 scalar + vector instructions came out of the issue slots of the two conv waves of its SIMD, the waves every
   // barrier of the prologue then waited for (16.16 -> 16.05 us per step).  Behind barrier W it is the youngest wave of its
   // SIMD with the longest dependent chain (fc1 -> fc2 -> softmax -> dh): priority 3 from there.
-  else if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
+  if (wave != V::NB && wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the younger half: at equal priority the older
                                                           // wave of a SIMD wins every arbitration and the younger one trails it
   if constexpr (TOK) {   // token staging [2][128][TKS] halves behind the fixed regions: zero once (padding tokens / channels stay 0)
     for (int i = tid; i < 2 * 128 * TKS / 8; i += V::NT) reinterpret_cast<uint4*>(smem + V::oW2)[i] = make_uint4(0u, 0u, 0u, 0u);
