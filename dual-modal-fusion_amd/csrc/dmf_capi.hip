@@ -883,6 +883,28 @@ int32_t dmf_grad_reduce_adam(const dmf_shape* s, int32_t B, const void* workspac
                     loss_hist, stream);
 }
 
+int32_t dmf_train_plan_steps(const dmf_shape* s, const dmf_input* in, float* theta, const float* pool_w, const int32_t* labels,
+                             float loss_scale, float* logits, float* loss, void* workspace, float* m, float* v, float lr,
+                             float beta1, float beta2, float eps, int32_t* adam_step_dev, int32_t* cursor_dev, float* loss_hist,
+                             int32_t n_steps, void* stream) {
+  if (s == nullptr || in == nullptr || theta == nullptr || labels == nullptr || logits == nullptr || loss == nullptr ||
+      adam_step_dev == nullptr || cursor_dev == nullptr)
+    return fail("%s", "null argument (dmf_train_plan_steps needs the device step count and cursor)");
+  if (in->mode != 1 || in->cursor != nullptr) return fail("%s", "dmf_train_plan_steps: gather mode, no plan cursor (the batches are consecutive)");
+  if (s->attention) return fail("%s", "dmf_train_plan_steps: late-fusion network only");
+  if (n_steps < 0 || in->B <= 0) return fail("%s", "dmf_train_plan_steps: negative step count or empty batch");
+  dmf_input ik = *in;
+  for (int32_t k = 0; k < n_steps; ++k) {
+    ik.xy = in->xy + (size_t)2 * in->B * k;
+    if (run_patch(s, &ik, MODE_TRAIN, theta, pool_w, labels + (size_t)in->B * k, nullptr, loss_scale, logits, loss, nullptr, workspace,
+                  adam_step_dev, stream))
+      return 1;
+    if (run_reduce(s, in->B, workspace, nullptr, theta, m, v, lr, beta1, beta2, eps, 0, adam_step_dev, cursor_dev, loss, loss_hist, stream))
+      return 1;
+  }
+  return 0;
+}
+
 int32_t dmf_grad_reduce_xgmi_adam(const dmf_shape* s, int32_t B, const void* workspace, float* theta, float* m,
                                   float* v, const dmf_xgmi_comm* comm, float lr, float beta1, float beta2, float eps,
                                   float grad_scale, const int32_t* adam_step_dev, int32_t* cursor_dev,

@@ -284,6 +284,17 @@ class TrainEngine:
             raise lib.DmfError('run_plan(%d): the loaded plan has %d steps, %d of them done' % (
                 steps, getattr(self, 'plan_steps', 0), self.host_cursor))
         done = 0
+        if steps_per_graph < 0 and self._native_loop_ok():
+            # the library's own loop: 2 launches per step enqueued from C, the batches read straight from the plan (no window,
+            # no graph): for a short run the fixed cost is one kernel launch instead of a window copy + a graph launch
+            k0 = self.host_cursor
+            inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, self.plan_xy[k0 * self.B:(k0 + steps) * self.B], B=self.B)
+            lib.train_plan_steps(self.shape, inp, self.theta, self.net.pool_w, self.plan_labels[k0 * self.B:(k0 + steps) * self.B],
+                                 1.0 / self.B, self.logits, self.loss, self.ws, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
+                                 self.dev_step, self.dev_cursor, self.loss_hist, steps)
+            self.step_count += steps
+            self.host_cursor += steps
+            return steps
         if steps_per_graph > 0 and self._graphable():
             # lr, betas and eps are launch arguments baked into the captured graph (reference: `scheduler.step()` changes
             # the optimiser's lr every epoch, mainsolver.py:60): a change invalidates the graph
@@ -307,6 +318,10 @@ class TrainEngine:
         for _ in range(steps - done):
             self._plan_step()
         return steps
+
+    def _native_loop_ok(self):
+        """run_plan(steps, steps_per_graph=-1): the C loop of dmf_train_plan_steps — late-fusion net, ADAM, one GPU, no scaler."""
+        return self.world == 1 and self.scaler is None and self.optim == 'ADAM' and not self.shape.attention
 
     def _graphable(self):
         """Can a step be captured in a hipGraph?  One GPU: yes.  The one-shot exchange: yes (it is part of the reduce launch).

@@ -71,6 +71,7 @@ def _load():
         'dmf_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, i32, f32, vp, vp, vp]),
         'dmf_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
         'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
+        'dmf_train_plan_steps': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
         'dmf_xgmi_sizes': (i32, [i64, i32, C.POINTER(i64), C.POINTER(i64)]),
         'dmf_xgmi_alloc': (i32, [i64, C.POINTER(vp)]),
         'dmf_xgmi_free': (i32, [vp]),
@@ -295,6 +296,14 @@ def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step, ada
     check(_lib.dmf_grad_reduce_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), _ptr(grad),
                                     lr, b1, b2, eps, step, _ptr(adam_step_dev), _ptr(cursor_dev), _ptr(loss),
                                     _ptr(loss_hist), _stream()))
+
+
+def train_plan_steps(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, m, v, lr, b1, b2, eps, adam_step_dev, cursor_dev,
+                     loss_hist, n_steps):
+    """n_steps fused train steps on consecutive batches of a resident plan, enqueued by one C loop (dmf_train_plan_steps)."""
+    check(_lib.dmf_train_plan_steps(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels), loss_scale, _ptr(logits),
+                                    _ptr(loss), _ptr(ws), _ptr(m), _ptr(v), lr, b1, b2, eps, _ptr(adam_step_dev), _ptr(cursor_dev),
+                                    _ptr(loss_hist), n_steps, _stream()))
 
 
 def grad_reduce_xgmi_adam(shape, B, ws, theta, m, v, comm, lr, b1, b2, eps, grad_scale, adam_step_dev, cursor_dev=None,

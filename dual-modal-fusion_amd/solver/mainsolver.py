@@ -146,7 +146,9 @@ class Solver(BaseSolver):
         losses = []
         if full:
             eng.load_plan(torch.cat([b[0] for b in full]), torch.cat([b[1] for b in full]))
-            eng.run_plan(len(full), int(self.cfg.get('steps_per_graph', 0)))
+            # steps_per_graph: N > 0 replays captured hipGraphs of N steps, 0 launches step by step from Python, -1 (default)
+            # hands the whole epoch to the library's launch loop (dmf_train_plan_steps) where that exists, else step by step
+            eng.run_plan(len(full), int(self.cfg.get('steps_per_graph', -1)))
             losses = eng.mean_losses().tolist()
         for xy, lab in batches:
             if xy.shape[0] != B:                                             # DataLoader keeps the short last batch

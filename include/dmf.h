@@ -206,6 +206,16 @@ int32_t dmf_grad_reduce_adam(const dmf_shape* shape, int32_t B, const void* work
 /* loss / loss_hist (may be NULL): when both are given, loss_hist[cursor] = mean(loss[0..B)) (fixed-order sum),
  * i.e. the value the reference prints per step (`loss.item()`, mainsolver.py:58) without a host sync. */
 
+/* The reference's whole inner loop `for batch in loader: zero_grad; forward; CE; backward; Adam.step` (mainsolver.py:49-55)
+ * over n_steps consecutive batches of a resident plan, as ONE call: step k = dmf_train_fwd_bwd on the B patches at
+ * in->xy + 2 B k with labels + B k, then dmf_grad_reduce_adam (device step count, cursor, loss history) — 2 n_steps launches
+ * enqueued by one C loop, nothing else between them.  in->mode must be 1 and in->cursor NULL; adam_step_dev and cursor_dev are
+ * required (device ints: steps taken so far, next row of loss_hist).  Late-fusion network, ADAM, one GPU. */
+int32_t dmf_train_plan_steps(const dmf_shape* shape, const dmf_input* in, float* theta, const float* pool_w,
+                             const int32_t* labels, float loss_scale, float* logits, float* loss, void* workspace,
+                             float* m, float* v, float lr, float beta1, float beta2, float eps,
+                             int32_t* adam_step_dev, int32_t* cursor_dev, float* loss_hist, int32_t n_steps, void* stream);
+
 /* ---- stage 2 of the two-stage path (solver/tostagesolver.py:259-346) ---------------------------------------
  * The stage-2 net takes ONE input, the four streams (ms, pan, ms_gan, pan_gan) stacked on the batch axis
  * (`torch.concat([data1..data4])`, tostagesolver.py:272), and is trained with `qua_loss`. */
