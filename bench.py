@@ -363,12 +363,13 @@ def main():
     value = world * B * K_steps / dt
 
     # ---- instrumented pass: mean duration of the dominant kernel, HIP events on the launch stream
-    n_inst = min(max(K_steps, 100), 200, plan_steps)     # (at least 100 launches, however short the timed region was)
+    n_inst = min(max(K_steps, 100), 200)                 # (at least 100 launches, however short the timed region was: batches repeat)
     alg_patch = 2 * ((2 if args.half else 4) * P * P * C + 4 * (S * P) * (S * P) * C2)     # --half: the primary bands are 2 bytes
     kern_ms = None
     if rank == 0 or world > 1:
-        inst_plan_xy = torch.from_numpy(xy_tab[mine[:n_inst * B]]).to(dev)
-        inst_lab = torch.from_numpy(lab_tab[mine[:n_inst * B]]).to(dev)
+        inst_idx = np.concatenate([mine[(i % plan_steps) * B:(i % plan_steps + 1) * B] for i in range(n_inst)])
+        inst_plan_xy = torch.from_numpy(xy_tab[inst_idx]).to(dev)
+        inst_lab = torch.from_numpy(lab_tab[inst_idx]).to(dev)
         theta2 = eng.theta.clone()
         # one event pair brackets GROUP consecutive launches of the kernel (each on its own batch of the plan): a pair around
         # a single 14-us launch also times the ~2 us the command processor spends on the two event packets themselves

@@ -12,3 +12,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --kernel-tra
 python3 tools/phase_profile_v2.py 256 > gpurun_out/r3_phase_stamps.txt 2>&1 || exit 1
 python3 tools/reduce_phase_profile.py > gpurun_out/r3_reduce_stamps.txt 2>&1 || exit 1
 echo collected
+bash tools/collect_r3_configs.sh > gpurun_out/r3_collect_configs.log 2>&1 || exit 1
+rm -rf gpurun_out/prof_r3attn
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r3attn -- python3 bench.py --config 2 --no-cpu --steps 300 --warmup 30 --kappa-steps 0 > gpurun_out/r3_attn_bench.log 2>&1 || exit 1
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --kappa-steps 0 2>/dev/null | grep '^{' > gpurun_out/r3_bench_line_steps20.json
+echo collected-all
