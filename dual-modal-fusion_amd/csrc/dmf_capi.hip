@@ -691,6 +691,15 @@ int32_t dmf_forward(const dmf_shape* s, const dmf_input* in, const float* theta,
   return run_patch(s, in, MODE_FWD, theta, pool_w, nullptr, nullptr, 0.f, logits, nullptr, pred, nullptr, nullptr, stream);
 }
 
+int32_t dmf_forward_ce(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w, const int32_t* labels,
+                       float* logits, float* loss, int32_t* pred, void* stream) {
+  if (in != nullptr && in->B == 0) return 0;
+  if (logits == nullptr || labels == nullptr || loss == nullptr) return fail("%s", "null logits/labels/loss");
+  if (s == nullptr || s->attention || force_v1() || !(in != nullptr && in->half ? patch_v2_supported(*s, MODE_FWD, 1) : patch_v2_supported(*s, MODE_FWD)))
+    return fail("%s", "dmf_forward_ce: no evaluation kernel with a fused cross-entropy for this shape (use dmf_forward)");
+  return run_patch(s, in, MODE_FWD, theta, pool_w, labels, nullptr, 0.f, logits, loss, pred, nullptr, nullptr, stream);
+}
+
 int32_t dmf_train_fwd_bwd(const dmf_shape* s, const dmf_input* in, const float* theta, const float* pool_w,
                           const int32_t* labels, float loss_scale, float* logits, float* loss, void* workspace,
                           int32_t* adam_step_dev, void* stream) {

@@ -1268,6 +1268,18 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
       // this patch's head vectors for the gradient reduce
       if ((MODE != MODE_BWD || a.logits != nullptr) && lane < K) a.logits[(size_t)b * K + lane] = lg;
       if (a.pred != nullptr && lane == 0) a.pred[b] = pred_b;
+      if constexpr (MODE == MODE_FWD) {
+        // evaluation with labels (dmf_forward_ce: the validation pass, mainsolver.py:62-76): the per-patch cross-entropy, by the
+        // training kernel's own formula
+        if (a.labels != nullptr && a.loss != nullptr) {
+          int label = ((cint*)a.labels)[boff + b];
+          label = label < 0 ? 0 : (label >= K ? K - 1 : label);
+          const float e = lane < K ? __expf(lg - mx) : 0.f;
+          const float se = wave_sum_dpp(e);
+          const float lgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lg), __builtin_amdgcn_readfirstlane(label)));
+          if (lane == 0) a.loss[b] = (mx + __logf(se)) - lgt;
+        }
+      }
       if constexpr (TR) {
         if (MODE == MODE_TRAIN && lane == 0) a.loss[b] = loss_b;
         const size_t hv = hv_index(b, lane, B);            // strip-major head vectors (dmf_shapes.h)

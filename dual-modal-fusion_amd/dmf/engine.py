@@ -425,6 +425,24 @@ class EvalEngine:
             lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits, self.pred)
         return self.logits[:n], self.pred[:n]
 
+    def ce_sum(self, xy, labels):
+        """Sum over the batch of the per-patch cross-entropy (device scalar, float64), from the evaluation launch itself
+        (dmf_forward_ce); None where the shape has no such kernel."""
+        n = xy.shape[0]
+        if n > self.B:
+            raise lib.DmfError('batch larger than the engine was built for')
+        if self.shape.attention or getattr(self, '_no_ce', False):
+            return None
+        if not hasattr(self, 'ce'):
+            self.ce = torch.zeros(self.B, device=self.scene.device)
+        inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xy)
+        try:
+            lib.forward_ce(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, labels, self.logits, self.ce, self.pred)
+        except lib.DmfError:
+            self._no_ce = True
+            return None
+        return self.ce[:n].double().sum()
+
     def confusion(self, xy_all, labels_all, matrix=None, process_group=None):
         """Confusion matrix [K,K] int64 (rows = prediction) over all given pixels; one D2H at the end.
         With a process group every rank classifies its contiguous shard of the pixels and the matrices are summed."""

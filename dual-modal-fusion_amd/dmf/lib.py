@@ -71,6 +71,7 @@ def _load():
         'dmf_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, i32, f32, vp, vp, vp]),
         'dmf_rmsprop_step': (i32, [vp, vp, vp, i64, f32, f32, f32, f32, vp, vp]),
         'dmf_grad_reduce_adam': (i32, [SP, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp]),
+        'dmf_forward_ce': (i32, [SP, IP, vp, vp, vp, vp, vp, vp, vp]),
         'dmf_train_plan_steps': (i32, [SP, IP, vp, vp, vp, f32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
         'dmf_xgmi_sizes': (i32, [i64, i32, C.POINTER(i64), C.POINTER(i64)]),
         'dmf_xgmi_alloc': (i32, [i64, C.POINTER(vp)]),
@@ -296,6 +297,13 @@ def grad_reduce_adam(shape, B, ws, theta, m, v, grad, lr, b1, b2, eps, step, ada
     check(_lib.dmf_grad_reduce_adam(C.byref(shape), B, _ptr(ws), _ptr(theta), _ptr(m), _ptr(v), _ptr(grad),
                                     lr, b1, b2, eps, step, _ptr(adam_step_dev), _ptr(cursor_dev), _ptr(loss),
                                     _ptr(loss_hist), _stream()))
+
+
+def forward_ce(shape, inp, theta, pool_w, labels, logits, loss, pred=None):
+    """Evaluation forward + per-patch cross-entropy in the same launch (dmf_forward_ce); raises DmfError where the shape has no
+    such kernel (the caller then uses forward() + its own loss)."""
+    check(_lib.dmf_forward_ce(C.byref(shape), C.byref(inp), _ptr(theta), _ptr(pool_w), _ptr(labels), _ptr(logits), _ptr(loss),
+                              _ptr(pred), _stream()))
 
 
 def train_plan_steps(shape, inp, theta, pool_w, labels, loss_scale, logits, loss, ws, m, v, lr, b1, b2, eps, adam_step_dev, cursor_dev,

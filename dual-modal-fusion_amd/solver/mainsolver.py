@@ -208,8 +208,13 @@ class Solver(BaseSolver):
             tot = torch.zeros((), dtype=torch.float64, device=self.DEVICE)
             with torch.no_grad():
                 for batch in self.valid_index_loader:
-                    logits, target, _, _ = self._forward_batch(batch)
-                    tot += ce(logits, target).double() * target.shape[0]
+                    xy, lab = self._xy_labels(batch)
+                    # the evaluation launch's own per-patch cross-entropy (dmf_forward_ce) where the shape has it ...
+                    part = self.eval_engine.ce_sum(xy.to(self.DEVICE), lab.to(self.DEVICE)) if hasattr(self.eval_engine, 'ce_sum') else None
+                    if part is None:                         # ... else torch's on the logits (attention network, generic kernel)
+                        logits, target, _, _ = self._forward_batch(batch)
+                        part = ce(logits, target).double() * target.shape[0]
+                    tot += part
             return float(tot.item())
         with torch.no_grad():
             for batch in (self.valid_index_loader if self.fast else self.valid_loader):

@@ -94,6 +94,11 @@ int64_t dmf_workspace_bytes(const dmf_shape* shape, int32_t B);
  * `pred = output.data.max(1)` (mainsolver.py:139,170).  logits [B, K]; pred [B] int32 may be NULL. */
 int32_t dmf_forward(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                     float* logits, int32_t* pred, void* stream);
+/* The same launch with the per-patch cross-entropy against labels [B] int32 written to loss [B] — the validation pass,
+ * `loss = self.loss(output, target.long())` under no_grad (mainsolver.py:62-76), by the training kernel's own formula.
+ * Fails (use dmf_forward + the caller's loss) for shapes that run the generic kernel and for the attention network. */
+int32_t dmf_forward_ce(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
+                       const int32_t* labels, float* logits, float* loss, int32_t* pred, void* stream);
 
 /* Forward of the network WITH the cross-modal attention block (shape->attention == 1; BASELINE configs[2]):
  * the conv stages emit bf16 token maps, then a matrix-core kernel (bf16 MFMA operands, fp32 accumulate) does the

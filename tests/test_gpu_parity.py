@@ -559,3 +559,32 @@ def test_attention_autograd_and_engine_steps():
                    for (_, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters())]).numpy()
     print('attention engine parameters after 3 steps: 99th percentile diff %.2e, max %.2e' % (np.percentile(d, 99), d.max()))
     assert np.percentile(d, 99) < 2e-4 and d.max() <= 2 * 3 * 1e-2 + 1e-6
+
+
+@pytest.mark.parametrize('name', ['hsi', 'tiny1', 'panms'])
+def test_forward_ce_matches_torch_cross_entropy(name):
+    """dmf_forward_ce (the validation pass's launch: evaluation forward + per-patch cross-entropy) against
+    torch.nn.functional.cross_entropy on the oracle's logits, labels at both ends of the class range included."""
+    from dmf import lib
+    C, C2, P, S, K = SHAPES[name]
+    cfg, ref, hip = nets(name)
+    H, W = 23, 19
+    A, Bm = _scene(name, H, W)
+    g = torch.Generator().manual_seed(4)
+    Bn = 97
+    xy = torch.stack([torch.randint(0, H, (Bn,), generator=g), torch.randint(0, W, (Bn,), generator=g)], 1).int()
+    t = torch.randint(0, K, (Bn,), generator=g)
+    t[0], t[1] = 0, K - 1
+    a = torch.stack([A[x:x + P, y:y + P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    b = torch.stack([Bm[S * x:S * x + S * P, S * y:S * y + S * P, :].permute(2, 0, 1) for x, y in xy.tolist()])
+    with torch.no_grad():
+        want_logits = ref(a, b)
+        want = torch.nn.functional.cross_entropy(want_logits, t, reduction='none')
+    Ad, Bd, xyd = A.cuda(), Bm.cuda(), xy.cuda()
+    inp = lib.input_gather(hip.shape, Ad, Bd, xyd)
+    logits = torch.empty(Bn, K, device='cuda'); loss = torch.full((Bn,), float('nan'), device='cuda')
+    pred = torch.empty(Bn, dtype=torch.int32, device='cuda')
+    lib.forward_ce(hip.shape, inp, hip.flat_parameters(), hip.pool_w, t.int().cuda(), logits, loss, pred)
+    assert_close(logits, want_logits, 1e-5, 0, 'forward_ce logits[%s]' % name)
+    assert_close(loss, want, 2e-5, 0, 'forward_ce loss[%s]' % name)
+    assert abs(loss.double().sum().item() - want.double().sum().item()) < 1e-4
