@@ -184,7 +184,7 @@ __device__ __forceinline__ void adam_apply(const ReduceArgs& a, int64_t p, float
 #ifdef DMF_STAMPS
 __device__ unsigned long long* g_rstamps = nullptr;
 #define RSTAMP_DECL unsigned long long rst_[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
-#define RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(rst_[i])); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rst_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RSTAMP_RT(i) do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rst_[i])); } while (0)
 #define RSTAMP_DUMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); RSTAMP(6); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     if ((threadIdx.x & 63) == 0 && g_rstamps != nullptr) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) \

@@ -54,7 +54,10 @@ namespace dmf {
 #ifdef DMF_STAMPS
 __device__ unsigned long long* g_v2stamps = nullptr;     // [block][16 waves][16 stamps]
 #define VSTAMP_DECL unsigned long long vst_[14] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
-#define VSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(vst_[i])); __builtin_amdgcn_sched_barrier(0); } while (0)
+// (the stamp WAITS for its own result: s_memtime returns like a scalar load, and a compiler that believes the value is there at
+// once may spill it and reuse the register pair — the result, landing late, then overwrites whatever lives there.  Found as a
+// memory fault of the 4-band instance of this diagnostic build, where 14 live stamps exhaust the scalar registers.)
+#define VSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define VSTAMP_W(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_[i])); } while (0)
 #define VSTAMP_RT(i) do { asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_[i])); } while (0)
 #define VSTAMP_DUMP() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0 && g_v2stamps != nullptr) { \

@@ -24,12 +24,13 @@ CONV = ['entry', 'prologue', 'gather issued', 'aux done', 'barrierW', 'barrier1'
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    panms = len(sys.argv) > 2 and sys.argv[2] == 'panms'        # the reference's own data shape: 4-band MS + PAN at 4x, 16x16 patches
+    panms = len(sys.argv) > 2 and sys.argv[2] in ('panms', 'qua')   # the reference's own data shape: 4-band MS + PAN at 4x, 16x16 patches
+    qua = len(sys.argv) > 2 and sys.argv[2] == 'qua'            # ... or the stage-2 stream shape: 4 bands, aux at the same resolution
     cfg = {'patch_size': 11, 'Categories_Number': 17, 'data_city': 's', 'DATA_DICT': {'s': {'size': [145, 145, 200]}},
            'scale': 1, 'aux_bands': 1, 'gmf': {'width': 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
     if panms:
-        cfg.update({'patch_size': 16, 'Categories_Number': 12, 'DATA_DICT': {'s': {'size': [145, 145, 4]}}, 'scale': 4})
-    primary, aux, label = synth.make_scene(145, 145, 4 if panms else 200, 1, 4 if panms else 1, seed=0)
+        cfg.update({'patch_size': 16, 'Categories_Number': 12, 'DATA_DICT': {'s': {'size': [145, 145, 4]}}, 'scale': 1 if qua else 4})
+    primary, aux, label = synth.make_scene(145, 145, 4 if panms else 200, 1, (1 if qua else 4) if panms else 1, seed=0)
     MS = data_padding(primary, cfg, 'ms').astype(np.float32)
     PAN = data_padding_aux(aux, cfg).astype(np.float32)
     net = Net(cfg).cuda()
