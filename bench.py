@@ -371,28 +371,37 @@ def main():
         inst_plan_xy = torch.from_numpy(xy_tab[inst_idx]).to(dev)
         inst_lab = torch.from_numpy(lab_tab[inst_idx]).to(dev)
         theta2 = eng.theta.clone()
-        # one event pair brackets GROUP consecutive launches of the kernel (each on its own batch of the plan): a pair around
-        # a single 14-us launch also times the ~2 us the command processor spends on the two event packets themselves
-        GROUP = 10
-        n_grp = max(n_inst // GROUP, 1)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_grp)]
+        # One event pair brackets GROUP consecutive launches of the kernel, each on its own batch of the plan, replayed from a
+        # captured graph: a pair around a single 12-us launch would also time the ~2 us the command processor spends on the two
+        # event packets, and launches enqueued one by one from Python (~10 us of host time each) leave the device waiting for
+        # the host.  (Back-to-back launches of THIS kernel: each still pays for the write-back of its predecessor's 2 MB of
+        # slab rows, which in the real step the reduce launch pays — rocprofv3's average inside the real step is ~5 % lower.)
+        GROUP = 50
+        n_rep = max((n_inst + GROUP - 1) // GROUP, 2)
         ws = eng.ws
-        torch.cuda.synchronize()
-        for g_ in range(n_grp):
-            inps = [lib.input_gather(eng.shape, scene.A, scene.B, inst_plan_xy[i * B:(i + 1) * B])
-                    for i in range(g_ * GROUP, min((g_ + 1) * GROUP, n_inst))]
-            ev[g_][0].record()
-            for k_, inp in enumerate(inps):
-                i = g_ * GROUP + k_
+        inps = [lib.input_gather(eng.shape, scene.A, scene.B, inst_plan_xy[(i % n_inst) * B:((i % n_inst) + 1) * B]) for i in range(GROUP)]
+
+        def group():
+            for i, inp in enumerate(inps):
+                lb = inst_lab[(i % n_inst) * B:((i % n_inst) + 1) * B]
                 if args.attention:
-                    lib.train_attn_fwd_bwd(eng.shape, inp, theta2, net.pool_w, inst_lab[i * B:(i + 1) * B], None, 1.0 / B,
-                                           eng.logits, eng.loss, ws, eng.attn_ws)
+                    lib.train_attn_fwd_bwd(eng.shape, inp, theta2, net.pool_w, lb, None, 1.0 / B, eng.logits, eng.loss, ws, eng.attn_ws)
                 else:
-                    lib.train_fwd_bwd(eng.shape, inp, theta2, net.pool_w, inst_lab[i * B:(i + 1) * B], 1.0 / B, eng.logits, eng.loss, ws)
-            ev[g_][1].record()
+                    lib.train_fwd_bwd(eng.shape, inp, theta2, net.pool_w, lb, 1.0 / B, eng.logits, eng.loss, ws)
+        group()                                            # (every kernel has run once before the capture)
         torch.cuda.synchronize()
-        kern_ms = float(np.mean([a.elapsed_time(b) / len(range(g_ * GROUP, min((g_ + 1) * GROUP, n_inst)))
-                                 for g_, (a, b) in enumerate(ev)][n_grp // 10:]))
+        gi = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gi):
+            group()
+        gi.replay()                                        # first replay of a graph: not timed
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_rep)]
+        torch.cuda.synchronize()
+        for a_, b_ in ev:
+            a_.record()
+            gi.replay()
+            b_.record()
+        torch.cuda.synchronize()
+        kern_ms = float(np.mean([a_.elapsed_time(b_) / GROUP for a_, b_ in ev]))
     losses = eng.mean_losses().numpy() if world == 1 else np.zeros(0)
 
     # ---- kappa: training continues to --kappa-steps (a fixed budget, not --steps), then the held-out split is classified on
