@@ -249,6 +249,9 @@ def main():
         else:
             dist.init_process_group(backend)
         pg = dist.group.WORLD
+        if os.environ.get('DMF_CU_SHARE') == '1':      # rehearsal on ONE GPU: every rank on its own share of the compute units
+            from dmf import xgmi as _xg                # (dmf.xgmi.cu_share_stream says why the exchange needs that there)
+            torch.cuda.set_stream(_xg.cu_share_stream(rank, world, dev))
     if args.config == '4':
         return main_stage2(args, dev, pg, rank, world, backend)
 

@@ -63,6 +63,33 @@ class Communicator:
         self._mapped, self._own = [], []
 
 
+def cu_share_stream(rank, world, device=None):
+    """A stream whose kernels run only on rank's contiguous share of the GPU's compute units (hipExtStreamCreateWithCUMask).
+
+    For REHEARSALS of the exchange with several ranks on ONE GPU (tests/test_gpu_dp.py, `DMF_CU_SHARE=1 bench.py --gpus N`
+    on a one-GPU box) — never needed on a node, where a rank's GPU holds its own kernels only.  Why it is needed there
+    (measured in round 3 with the three processes of the test): the blocks of the reduce launch WAIT inside the exchange, one
+    of them fits a compute unit beside nothing else of its kind (5 waves, 135 registers), and the patch kernel needs a
+    compute unit to itself.  The two ranks that reach the exchange first cover all 256 units with waiting blocks
+    (157 + 99 in the test), the third rank's kernels find no unit, its flags never come and everybody times out: a dead-lock
+    of residency, not of the protocol (with two ranks the second always finds free units).  On its own share of the units a
+    rank's blocks are dispatched in order whatever the peers do, and all ranks work through the same block indices."""
+    import ctypes
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    hip = ctypes.CDLL('libamdhip64.so')              # (the runtime torch has loaded)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    lo, hi = rank * n_cu // world, (rank + 1) * n_cu // world
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(lo, hi):
+        mask[i // 32] |= 1 << (i % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        raise lib.DmfError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 def _all_agree(ok, group, device):
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)

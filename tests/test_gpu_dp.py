@@ -3,14 +3,16 @@ over gloo (RCCL refuses two ranks on one device); the code path is the one `benc
 dmf_grad_reduce -> all-reduce(sum) of ONE flat gradient -> dmf_adam_step(grad_scale = 1/N).  After 3 steps the
 2-rank parameters must equal those of a single process that trains on the concatenated global batches.
 
-The same check runs over the one-shot xGMI exchange (dmf_grad_reduce_xgmi_adam, HIP-IPC mapped peer buffers): 2
-ranks stepping eagerly and 2 ranks replaying a captured hipGraph of the whole data-parallel step; on the one-GPU
-box the "peers" are processes on the same device, which exercises the IPC mapping, flags, parities and the
-rank-ordered sum, not the xGMI links themselves.  The exchange makes a kernel wait for a kernel of ANOTHER process; on
-a shared GPU that only works while the scheduler runs both side by side (observed: always with 2 processes, not always
-with 3), so a wait that times out is reported as an EXPECTED FAILURE with that reason (never a pass, never a silent skip) — wrong
-sums always fail.  The 3-rank case is the one that exposed the reader-side caching of the first (pull) design
-(csrc/dmf_xgmi.h); it runs against the push design with the store-acknowledgement wait."""
+The same check runs over the one-shot xGMI exchange (dmf_grad_reduce_xgmi_adam, HIP-IPC mapped peer buffers) with 2, 3 and
+4 ranks, stepping eagerly and replaying a captured hipGraph of the whole data-parallel step; on the one-GPU box the "peers"
+are processes on the same device, which exercises the IPC mapping, flags, parities and the rank-ordered sum, not the xGMI
+links themselves.  The exchange makes a kernel wait for a kernel of ANOTHER process.  With three and more processes on ONE
+GPU that dead-locks on residency (measured in round 3: the ranks that reach the exchange first fill every compute unit with
+waiting blocks and the last rank's kernels find no unit), so each rank of those cases launches on a stream that owns a
+share of the compute units (`dmf.xgmi.cu_share_stream`) — its "own GPU".  A wait that times out all the same is reported as an
+EXPECTED FAILURE with that reason (never a pass, never a silent skip); wrong sums always fail.  The 3-rank case is the one
+that exposed the reader-side caching of the first (pull) design (csrc/dmf_xgmi.h); it runs against the push design with
+the store-acknowledgement wait."""
 import os
 import sys
 
@@ -63,6 +65,8 @@ def _train_xgmi(rank, world, port, q, graph_steps):
                 q.put('timeout')
             dist.destroy_process_group()
             return
+    if world >= 3:                   # every rank on its own compute units, as on a node (why: dmf.xgmi.cu_share_stream)
+        torch.cuda.set_stream(xgmi.cu_share_stream(rank, world))
     eng = TrainEngine(net, Scene(MS, PAN, 'cuda:0'), GB // world, lr=1e-2, process_group=pg, comm=comm)
     gxy, glab = xy[:NS * GB].reshape(NS, GB, 2), lab[:NS * GB].reshape(NS, GB)
     lo, hi = shard_batch(GB, rank, world)
@@ -132,7 +136,7 @@ def _run_ranks(target, world, extra):
     return out
 
 
-@pytest.mark.parametrize('world,graph_steps', [(2, 0), (2, 4), (3, 4)])
+@pytest.mark.parametrize('world,graph_steps', [(2, 0), (2, 4), (3, 0), (3, 4), (4, 4)])
 def test_xgmi_exchange_dp_equals_single_rank_global_batch(world, graph_steps):
     many = _run_ranks(_train_xgmi, world, (graph_steps,))
     if isinstance(many, str):
