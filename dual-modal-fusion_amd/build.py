@@ -57,8 +57,11 @@ def build(force=False, verbose=True, stamps=False, shapes=None, defines=(), suff
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     shapes = shapes or os.environ.get('DMF_EXTRA_SHAPES')
     extra = extra_shapes(shapes)
+    extra_flags = {k: list(v) for k, v in EXTRA.items()}
+    for name, var in (('dmf_patch_v2.hip', 'DMF_V2_FLAGS'), ('dmf_attention.hip', 'DMF_ATTN_FLAGS')):   # A/B variants only
+        extra_flags[name] = extra_flags.get(name, []) + os.environ.get(var, '').split()
     defs = (['-DDMF_STAMPS'] if stamps else []) + (['-DDMF_V2_EXTRA_SHAPES(X)=' + extra] if extra else []) + ['-D' + d for d in defines]
-    tag = hashlib.sha1(' '.join(FLAGS + defs + [repr(sorted(EXTRA.items()))]).encode()).hexdigest()[:8]
+    tag = hashlib.sha1(' '.join(FLAGS + defs + [repr(sorted(extra_flags.items()))]).encode()).hexdigest()[:8]
     out = OUT.replace('.so', '_stamps.so') if stamps else OUT
     if suffix:
         out = OUT.replace('.so', '_%s.so' % suffix)
@@ -68,7 +71,7 @@ def build(force=False, verbose=True, stamps=False, shapes=None, defines=(), suff
         o = os.path.join(OBJ, '%s.%s.o' % (os.path.basename(s), tag))
         objs.append(o)
         if force or _newer(o, [s] + HDR + [os.path.abspath(__file__)]):
-            jobs.append([hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + defs + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + extra_flags.get(os.path.basename(s), []) + defs + ['-c', s, '-o', o])
     tagfile = out + '.tag'
     relink = bool(jobs) or _newer(out, objs) or not os.path.exists(tagfile) or open(tagfile).read() != tag
     if not relink:

@@ -1198,13 +1198,16 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
       // fc1 + ReLU: lane j, its weight row in registers, z broadcast from LDS
       float h;
       {
-        float s0 = bh, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        // four running sums, packed as the register pairs a 16-byte read delivers ((x, y), (z, w)): left to itself the
+        // compiler pairs (x, z) and (y, w) and spends six moves per read on the shuffle
+        v2f s01 = (v2f){bh, 0.f}, s23 = (v2f){0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < F2 / 4; ++q) {
           const float4 zv = *reinterpret_cast<const float4*>(zbuf + 4 * q);
-          s0 = fmaf(w1r[q].x, zv.x, s0); s1 = fmaf(w1r[q].y, zv.y, s1); s2 = fmaf(w1r[q].z, zv.z, s2); s3 = fmaf(w1r[q].w, zv.w, s3);
+          s01 = pk_fma((v2f){w1r[q].x, w1r[q].y}, (v2f){zv.x, zv.y}, s01);
+          s23 = pk_fma((v2f){w1r[q].z, w1r[q].w}, (v2f){zv.z, zv.w}, s23);
         }
-        h = fmaxf((s0 + s1) + (s2 + s3), 0.f);
+        h = fmaxf((s01.x + s01.y) + (s23.x + s23.y), 0.f);
       }
       sH[lane] = h;
       VSTAMP(2);
@@ -1220,14 +1223,15 @@ __builtin_nontemporal_store(v.x, slab);       // (nt beats sc1 / sc0 sc1 / plain
       float lg;
       {
         const int kr = lane < K4 ? lane : K4 - 1;
-        float s0 = bk, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        v2f s01 = (v2f){bk, 0.f}, s23 = (v2f){0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < H / 4; ++q) {
           const float4 wv = *reinterpret_cast<const float4*>(sW2 + kr * V::W2S + 4 * q);
           const float4 hv = *reinterpret_cast<const float4*>(sH + 4 * q);
-          s0 = fmaf(wv.x, hv.x, s0); s1 = fmaf(wv.y, hv.y, s1); s2 = fmaf(wv.z, hv.z, s2); s3 = fmaf(wv.w, hv.w, s3);
+          s01 = pk_fma((v2f){wv.x, wv.y}, (v2f){hv.x, hv.y}, s01);
+          s23 = pk_fma((v2f){wv.z, wv.w}, (v2f){hv.z, hv.w}, s23);
         }
-        lg = lane < K ? (s0 + s1) + (s2 + s3) : -INFINITY;
+        lg = lane < K ? (s01.x + s01.y) + (s23.x + s23.y) : -INFINITY;
       }
       VSTAMP(3);
       const float mx = wave_max_dpp(lg);
