@@ -17,7 +17,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NAMES = ('dmf_patch_kernel.hip', 'dmf_patch_v2.hip', 'dmf_attention.hip', 'dmf_qua.hip', 'dmf_capi.hip')
+NAMES = ('dmf_patch_v2.hip', 'dmf_attention.hip', 'dmf_qua.hip', 'dmf_capi.hip')
 SRC = [os.path.join(HERE, 'csrc', n) for n in NAMES]
 HDR = [os.path.join(HERE, 'csrc', n) for n in ('dmf_shapes.h', 'dmf_kargs.h', 'dmf_lanes.h', 'dmf_xgmi.h')] + [os.path.join(os.path.dirname(HERE), 'include', 'dmf.h')]
 OUT = os.path.join(HERE, 'dmf', 'libdmf_hip.so')

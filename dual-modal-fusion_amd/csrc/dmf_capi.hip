@@ -498,16 +498,10 @@ __global__ __launch_bounds__(256) void pan2ms_kernel(const double* pan, int pitc
 
 using namespace dmf;
 
-// DMF_PATCH_V1=1 forces the generic patch kernel everywhere (A/B runs)
-static bool force_v1() {
-  static const bool f = [] { const char* e = getenv("DMF_PATCH_V1"); return e != nullptr && e[0] == '1'; }();
-  return f;
-}
-
-// the conv launches of the attention network: the v2 kernel where it is built for the shape, else the generic one
+// the conv launches of the attention network (MODE_TOKENS, MODE_DENSE)
 static hipError_t conv_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st) {
-  if (!force_v1() && patch_v2_supported(s, mode)) return patch_v2_dispatch(s, mode, a, st);
-  return patch_dispatch(s, mode, a, st);
+  if (!patch_v2_supported(s, mode)) return hipErrorInvalidValue;
+  return patch_v2_dispatch(s, mode, a, st);
 }
 
 extern "C" {
@@ -517,21 +511,18 @@ const char* dmf_last_error(void) { return g_err; }
 
 int32_t dmf_shape_supported(const dmf_shape* s) {
   if (s == nullptr) return fail("%s", "null shape");
-  // the generic kernel's instances carry every mode (attention included); the v2 table adds late-fusion shapes
-  if (patch_shape_supported(*s)) return 0;
-  if (!s->attention && !force_v1() && patch_v2_supported(*s, MODE_TRAIN)) return 0;
+  if (s->attention ? (patch_v2_supported(*s, MODE_TOKENS) && attn_shape_supported(*s)) : patch_v2_supported(*s, MODE_TRAIN)) return 0;
   snprintf(g_err, sizeof(g_err),
-           "no compiled kernel instance for C=%d C2=%d P=%d S=%d F=%d G=%d H=%d K=%d attention=%d; compiled (C/C2/P/S/F/G): "
-           "generic kernel 200/1/11/1/40/10 200/1/11/1/32/8 224/3/11/1/32/8 4/1/16/4/40/1 8/1/5/4/40/2 8/1/5/1/40/2 4/1/16/1/40/1 "
-           "4/1/5/1/40/1 (all modes, K <= 64); late fusion only:%s (subject to 160 KiB of LDS at this K)",
+           "no compiled kernel instance for C=%d C2=%d P=%d S=%d F=%d G=%d H=%d K=%d attention=%d; compiled (C/C2/P/S/F/G):%s "
+           "(K <= 64, subject to 160 KiB of LDS at this K; attention: 200/1/11/1/40/10 and 8/1/5/1/40/2 with E = 96, 3 heads); "
+           "`python dual-modal-fusion_amd/build.py --shapes FILE` adds rows",
            s->C, s->C2, s->P, s->S, s->F, s->G, s->H, s->K, s->attention, patch_v2_shape_list());
   return 1;
 }
 
 int32_t dmf_patch_variant(const dmf_shape* s, int32_t mode) {   // the same decision as run_patch / dmf_shape_supported
   if (s == nullptr) return 0;
-  if (!force_v1() && !s->attention && patch_v2_supported(*s, mode)) return 2;
-  return patch_shape_supported(*s) ? 1 : 0;
+  return patch_v2_supported(*s, mode) ? 2 : 0;
 }
 
 int32_t dmf_param_layout(const dmf_shape* s, int64_t offsets[17]) {
@@ -584,13 +575,11 @@ static int run_patch(const dmf_shape* s, const dmf_input* in, int mode, const fl
     a.ws_dh = ws + w.dh;
     a.ws_dl = ws + w.dl;
   }
-  // the wave-per-channel-block kernel where it is built for the shape; DMF_PATCH_V1=1 forces the generic kernel (A/B runs)
-  // (S > 1 on the v2 kernel: the aux patch image is fetched in 16-byte LDS-DMA pieces whose source addresses are only
-  // dword aligned when the aux row pitch is not a multiple of 4 floats — the reference pads a 1024-wide PAN to 1087; the
-  // buffer loads take that: tests/test_gpu_parity.py::test_aux_scene_pitch_not_a_multiple_of_four)
-  if (in->half || (!force_v1() && patch_v2_supported(*s, mode)))
-    return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel (v2) launch");
-  return check(patch_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
+  // (S > 1: the aux patch image is fetched in 16-byte LDS-DMA pieces whose source addresses are only dword aligned when the
+  // aux row pitch is not a multiple of 4 floats — the reference pads a 1024-wide PAN to 1087; the buffer loads take that:
+  // tests/test_gpu_parity.py::test_aux_scene_pitch_not_a_multiple_of_four)
+  if (!patch_v2_supported(*s, mode, in->half)) return fail("%s", "no compiled kernel instance for this shape / mode (dmf_shape_supported names the rows)");
+  return check(patch_v2_dispatch(*s, mode, a, static_cast<hipStream_t>(stream)), "patch kernel launch");
 }
 
 int64_t dmf_attn_workspace_bytes(const dmf_shape* s, int32_t B) {
@@ -695,7 +684,7 @@ int32_t dmf_forward_ce(const dmf_shape* s, const dmf_input* in, const float* the
                        float* logits, float* loss, int32_t* pred, void* stream) {
   if (in != nullptr && in->B == 0) return 0;
   if (logits == nullptr || labels == nullptr || loss == nullptr) return fail("%s", "null logits/labels/loss");
-  if (s == nullptr || s->attention || force_v1() || !(in != nullptr && in->half ? patch_v2_supported(*s, MODE_FWD, 1) : patch_v2_supported(*s, MODE_FWD)))
+  if (s == nullptr || s->attention || !(in != nullptr && in->half ? patch_v2_supported(*s, MODE_FWD, 1) : patch_v2_supported(*s, MODE_FWD)))
     return fail("%s", "dmf_forward_ce: no evaluation kernel with a fused cross-entropy for this shape (use dmf_forward)");
   return run_patch(s, in, MODE_FWD, theta, pool_w, labels, nullptr, 0.f, logits, loss, pred, nullptr, nullptr, stream);
 }
@@ -753,7 +742,7 @@ int32_t dmf_half_supported(const dmf_shape* s) {
 
 int32_t dmf_unit_supported(const dmf_shape* s) {
   if (s == nullptr) return fail("%s", "null shape");
-  if (force_v1() || s->attention || !patch_v2_supported(*s, MODE_UNIT))
+  if (s->attention || !patch_v2_supported(*s, MODE_UNIT))
     return fail("no unit-gradient kernel for this shape (instances C/C2/P/S/F/G:%s)", patch_v2_shape_list());
   return 0;
 }
@@ -1079,7 +1068,6 @@ int32_t dmf_pan2ms(const double* pan, int32_t pitch, int32_t H, int32_t W, doubl
 #ifdef DMF_STAMPS
 int32_t dmf_debug_set_reduce_stamps(void* p) { return check(hipMemcpyToSymbol(HIP_SYMBOL(dmf::g_rstamps), &p, sizeof(p)), "set_reduce_stamps"); }
 int32_t dmf_debug_set_attn_stamps(void* p) { return check(dmf::set_attn_stamps(static_cast<unsigned long long*>(p)), "set_attn_stamps"); }
-int32_t dmf_debug_set_stamps(void* p) { return check(dmf::set_stamps(static_cast<unsigned long long*>(p)), "set_stamps"); }
 int32_t dmf_debug_set_v2_stamps(void* p) { return check(dmf::set_v2_stamps(static_cast<unsigned long long*>(p)), "set_v2_stamps"); }
 #endif
 

@@ -37,7 +37,7 @@ enum { MODE_FWD = 0, MODE_TRAIN = 1, MODE_BWD = 2, MODE_TOKENS = 3, MODE_DENSE =
 // UNIT (v2 kernel only): forward + the conv backward for a UNIT gradient on every pooled feature; `slab` then is
 // [B][SLAB], one row of unit gradients per PATCH (dmf_forward_unit / dmf_backward_unit: a loss that couples the batch).
 
-// patch kernels (dmf_patch_kernel.hip, dmf_patch_v2.hip)
+// patch kernel (dmf_patch_v2.hip)
 struct KArgs {
   dmf_input in;
   const float* theta;
@@ -62,8 +62,6 @@ struct KArgs {
   const float* dYb;     // MODE_DENSE: dL/d(spat_b output) [B][F][P][RS]
   int32_t K;
 };
-int patch_shape_supported(const dmf_shape& s);
-hipError_t patch_dispatch(const dmf_shape& s, int mode, const KArgs& a, hipStream_t st);
 // wave-per-channel-block kernel (dmf_patch_v2.hip): FWD / TRAIN / BWD of the shapes it is built for
 int patch_v2_supported(const dmf_shape& s, int mode, int half = 0);   // half: dmf_input.half (fp16 primary scene)
 const char* patch_v2_half_shape_list();
@@ -115,7 +113,6 @@ hipError_t launch_band_mean(const float* x, int layout, int64_t n_img, int64_t n
 
 #ifdef DMF_STAMPS
 hipError_t set_attn_stamps(unsigned long long* p);
-hipError_t set_stamps(unsigned long long* p);
 hipError_t set_v2_stamps(unsigned long long* p);
 #endif
 

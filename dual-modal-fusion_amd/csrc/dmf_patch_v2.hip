@@ -2,8 +2,8 @@
 //
 // Replaces (reference): `output = self.cur_model(data1, data2)`, `loss = self.loss(output, target.long())`,
 // `loss.backward()` — solver/mainsolver.py:52-54 — and the eval forward + argmax (mainsolver.py:109,139,169-170).
-// Arithmetic: oracle/gmfnet_ref.py.  Same inputs, outputs and workspace contract as dmf_patch_kernel.hip (which
-// stays the generic kernel for what this one has no instance of: misaligned band groups, K too large for its LDS budget).
+// Arithmetic: oracle/gmfnet_ref.py.  The ONLY patch kernel since round 3 (round 1's generic kernel, which also took band
+// groups that are not whole 16-byte chunks — 200 bands at gmf.width 32 — was retired with that shape).
 //
 // Measured facts this design is built on (tools/valu_rate.hip, tools/phase_profile_v2.py on MI355X):
 //   * A SIMD issues one vector instruction per ~3.2 (v_fmac) to ~4.9 (DPP, packed) cycles however many waves it hosts,

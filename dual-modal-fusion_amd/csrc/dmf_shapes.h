@@ -15,21 +15,10 @@ struct Shape {
   static constexpr int P2 = P * P;          // pixels (tokens) per patch
   static constexpr int Cg = C / G;          // bands per spectral group
   static constexpr int M = F / G;           // outputs per spectral group
-  // MISAL: a group's first band is not 16-byte aligned in the pixel row (Cg % 4 != 0).  The kernel then reads the
-  // group through aligned 16-byte chunks that start up to 3 bands early (lead = (g*Cg) & 3) and skips the slots that
-  // belong to the neighbours; supported when a wavefront owns a whole group (M == 4).
-  static constexpr bool MISAL = (Cg % 4) != 0;
   static constexpr int SP = S * P;          // aux patch side
   static constexpr int PB = SP * SP;        // aux pixels per patch
   static constexpr int TB = C2 * S * S;     // taps of the lift conv
   static constexpr int F2 = 2 * F;
-  // threads per workgroup (one workgroup per CU): one 16-lane row group per feature channel, so that every
-  // reduction over patch rows is a 4-step shuffle inside a wavefront; at least 512 (head mapping)
-  static constexpr int NT = (F * 16 <= 512) ? 512 : ((F * 16 + 63) / 64) * 64;
-  static constexpr int NW = NT / 64;
-  static constexpr int NB = F / 4;          // channel blocks; wave b (< NB) owns channels 4b..4b+3 end to end
-  // LDS row stride of the Y1 maps (floats); the X-tile stride is chosen in Lds<> (dmf_patch_kernel.hip)
-  static constexpr int Fs = F + 1;          // odd: (channel,row)-mapped b32 reads of Y1 spread over all banks
   // flat parameter offsets (floats) — order documented in include/dmf.h
   static constexpr int oA1w = 0;
   static constexpr int oA1b = oA1w + F * Cg;
@@ -46,14 +35,13 @@ struct Shape {
   static constexpr int SLAB = (NCONV + 31) & ~31;   // slab row pitch (floats)
 
   static_assert(C % G == 0 && F % G == 0, "groups must divide C and F");
-  static_assert(Cg % 4 == 0 || M == 4, "bands per group: a multiple of 4 (16-byte chunks), or one wavefront per group");
-  static_assert(F % 4 == 0 && M % 4 == 0, "a wavefront owns a block of 4 channels inside one spectral group");
-  static_assert(P <= 16, "one 16-lane group holds the rows of a patch");
-  static_assert(F * 16 <= NT && NT <= 1024, "one 16-lane row group per channel");
-  static_assert(H * 8 <= NT && H <= 64 && 4 * F2 <= NT, "head mapping");
+  static_assert(Cg % 4 == 0, "bands per group: whole 16-byte chunks");
+  static_assert(F % 4 == 0, "feature channels in fours (the reduce launch's tiles)");
+  static_assert(P <= 16, "the rows of a patch are the lanes of (at most) one 16-lane group");
+  static_assert(H <= 64, "head mapping: one lane per hidden unit");
 };
 
-// run-time mirror of the layout (host side + generic kernels)
+// run-time mirror of the layout (host side)
 struct Layout {
   int C, C2, P, S, F, G, H, K, attention, E;
   int Cg, TB, F2, NCONV, SLAB;

@@ -73,8 +73,8 @@ const char* dmf_last_error(void);
 int32_t dmf_shape_supported(const dmf_shape* shape);
 
 /* Which patch kernel dmf_forward (mode 0), dmf_train_fwd_bwd (1) or dmf_backward_dlogits (2) launches for this shape:
- * 2 = the wave-per-channel-segment kernel (csrc/dmf_patch_v2.hip), 1 = the generic kernel (csrc/dmf_patch_kernel.hip),
- * 0 = no instance.  Reporting only (bench.py names the kernel it times); the arithmetic contract is the same. */
+ * 2 = the wave-per-channel-segment kernel (csrc/dmf_patch_v2.hip), 0 = no instance.  (1 was round 1's generic kernel,
+ * retired in round 3.)  Reporting only (bench.py names the kernel it times). */
 int32_t dmf_patch_variant(const dmf_shape* shape, int32_t mode);
 
 /* Flat parameter vector theta (fp32).  Tensor order and offsets (in floats):

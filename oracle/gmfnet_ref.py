@@ -63,12 +63,11 @@ def arch_from_cfg(cfg):
 
 
 def auto_groups(C, width):
-    """Largest G <= 16 with C % G == 0, width % G == 0, whole 4-channel blocks per group ((width/G) % 4 == 0: a wavefront
-    owns 4 channels of one group) and band groups the kernel can read: 16-byte chunks per group ((C/G) % 4 == 0), or any
-    group size when a wavefront owns a whole group (width/G == 4; it then reads through aligned chunks)."""
+    """Largest G <= 16 with C % G == 0, width % G == 0, whole 4-channel blocks per group ((width/G) % 4 == 0) and band groups
+    the kernel reads as whole 16-byte chunks ((C/G) % 4 == 0)."""
     best = 1
     for g in range(1, 17):
-        if C % g == 0 and width % g == 0 and (width // g) % 4 == 0 and ((C // g) % 4 == 0 or width // g == 4):
+        if C % g == 0 and width % g == 0 and (width // g) % 4 == 0 and (C // g) % 4 == 0:
             best = g
     return best
 

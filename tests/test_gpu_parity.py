@@ -17,7 +17,6 @@ SHAPES = {
     'tiny': (8, 1, 5, 4, 5),
     'tiny1': (8, 1, 5, 1, 5),
     'hsi': (200, 1, 11, 1, 17),
-    'hsi32': (200, 1, 11, 1, 17),    # gmf.width 32: 8 groups of 25 bands (misaligned groups), 8 wavefronts
     'hsi224': (224, 3, 11, 1, 17),
     'panms': (4, 1, 16, 4, 12),
     'qua': (4, 1, 16, 1, 12),        # stage 2 of the two-stage path: one 4-band stream + its band mean
@@ -33,7 +32,7 @@ def make_cfg(name):
     C, C2, P, S, K = SHAPES[name]
     return {'patch_size': P, 'Categories_Number': K, 'data_city': 's', 'DATA_DICT': {'s': {'size': [64, 64, C]}},
             'scale': S, 'aux_bands': C2,
-            'gmf': {'width': 32 if name in ('hsi224', 'hsi32', 'hsi224p9') else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
+            'gmf': {'width': 32 if name in ('hsi224', 'hsi224p9') else 40, 'hidden': 64, 'pool_sigma': 2.5, 'attention': 0}}
 
 
 def nets(name, seed=0):
@@ -79,13 +78,13 @@ def assert_close(got, want, atol, rtol, what):
         np.unravel_index(int(err.argmax()), tuple(err.shape)) if err.dim() else ())
 
 
-ALL = ['tiny', 'tiny1', 'hsi', 'hsi32', 'hsi224', 'panms', 'qua', 'quatiny', 'hsi9', 'hsi7', 'hsi224p9']
+ALL = ['tiny', 'tiny1', 'hsi', 'hsi224', 'panms', 'qua', 'quatiny', 'hsi9', 'hsi7', 'hsi224p9']
 
 
 @pytest.mark.parametrize('name', ALL)
 @pytest.mark.parametrize('B', [1, 37, 300])
 def test_forward_patches(name, B):
-    if name in ('hsi224', 'hsi32', 'panms', 'hsi224p9') and B == 300:
+    if name in ('hsi224', 'panms', 'hsi224p9') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -137,7 +136,7 @@ def test_forward_gather_and_pred(name):
 @pytest.mark.parametrize('B', [3, 64, 300])
 def test_train_fwd_bwd_grads(name, B):
     from dmf import lib
-    if name in ('hsi224', 'hsi32', 'panms', 'hsi224p9') and B == 300:
+    if name in ('hsi224', 'panms', 'hsi224p9') and B == 300:
         B = 260
     cfg, ref, hip = nets(name)
     a, b, t = rand_batch(name, B)
@@ -233,7 +232,7 @@ def test_aux_scene_pitch_not_a_multiple_of_four(name, extra):
     assert_close(fl, want_logits, 1e-5, 0, 'eval logits [%s, pitch %% 4 = %d]' % (name, extra))
 
 
-@pytest.mark.parametrize('name', ['tiny', 'hsi', 'hsi32'])
+@pytest.mark.parametrize('name', ['tiny', 'hsi', 'hsi224'])
 def test_train_gather_equals_patches(name):
     """Both input modes feed the same arithmetic: bit-identical logits, loss and gradient."""
     from dmf import lib
