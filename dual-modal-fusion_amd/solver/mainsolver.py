@@ -124,7 +124,15 @@ class Solver(BaseSolver):
                                   eps=hp['eps'], process_group=self.process_group,
                                   comm=self.comm if hp['optimizer'] == 'ADAM' else None, optimizer=hp['optimizer'],
                                   momentum=hp.get('momentum', 0.0), alpha=hp.get('alpha', 0.99))
-        self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
+        self.eval_engine = EvalEngine(self.cur_model, self.scene, self._eval_chunk())
+
+    def _eval_chunk(self):
+        """Pixels per evaluation launch of the fast path.  `test_batchsize` / `color_batchsize` size the reference's host-fed
+        loader (mainsolver.py:90-101,155-163); with the scene resident every pixel is independent of its batch, and a launch of
+        256 patches is bound by the host (0.13 of the HBM roof on a 512x512x224 scene) where 16,384 reach 0.62
+        (tools/eval_bench.py; identical class maps)."""
+        big = 4096 if self.cur_model.arch['attention'] else 16384
+        return max(self.cfg['test_batchsize'], self.cfg['color_batchsize'], big)
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize'] // self.world
@@ -239,7 +247,7 @@ class Solver(BaseSolver):
 
     def _make_eval_engine(self):
         from dmf.engine import EvalEngine
-        self.eval_engine = EvalEngine(self.cur_model, self.scene, max(self.cfg['test_batchsize'], self.cfg['color_batchsize']))
+        self.eval_engine = EvalEngine(self.cur_model, self.scene, self._eval_chunk())
 
     def test(self):
         time1 = time.time()
@@ -249,8 +257,9 @@ class Solver(BaseSolver):
         K = self.cfg['Categories_Number']
         full = bool(self.cfg['test'].get('full', 0))
         with torch.no_grad():
-            if self.fast and full and self.world > 1:
-                # whole split, sharded: every rank classifies its part of the pixels, the matrices are summed
+            if self.fast and full:
+                # whole split in evaluation chunks of the engine's own size (data parallel: every rank classifies its part
+                # of the pixels, the matrices are summed)
                 parts = [self._xy_labels(b) for b in self.test_index_loader]
                 matrix = self.eval_engine.confusion(torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
                                                     process_group=self.process_group)
@@ -294,7 +303,7 @@ class Solver(BaseSolver):
             for use, loaders in ((self.cfg['color']['supervised'], (self.color_index_loader1, self.color_loader1)),
                                  (self.cfg['color']['unsupervised'], (self.color_index_loader2, self.color_loader2))):
                 m = torch.zeros(H, W, dtype=torch.int32, device=self.DEVICE) if self.fast else np.zeros([H, W], dtype=np.int64)
-                if use and self.fast and self.world > 1:
+                if use and self.fast:      # all pixels, in evaluation chunks of the engine's own size (_eval_chunk)
                     xy_all = torch.cat([self._xy_labels(b)[0] for b in loaders[0]])
                     m = self.eval_engine.label_map(xy_all, H, W, process_group=self.process_group)
                 elif use:

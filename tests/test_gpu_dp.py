@@ -294,11 +294,15 @@ def test_xgmi_protocol_many_ranks_one_process(world):
         for q in range(world):
             c.data[q], c.flags[q] = bufs[q]
         comms.append(c)
-    streams = [torch.cuda.Stream() for _ in range(world)]
-    # Every stream runs one trivial kernel to completion BEFORE the first exchange.  The first launch on a new stream creates
-    # its hardware queue, and that does not happen beside a kernel that is already spinning on another stream: in round 2
-    # this test timed out in "round 1" — the first launch per stream — and never later (gpurun_out/r2_stage2d.log).  The
-    # per-GPU processes of a real run reach their first exchange on a stream that has run kernels for a long time.
+    # Every rank's stream must own a HARDWARE queue: HIP multiplexes the streams of a process onto a few queues
+    # (GPU_MAX_HW_QUEUES, 4 by default), and two ranks that share one run their kernels one after the other — the first waits
+    # for a peer that is queued behind it, until the time-out.  Which streams share depends on how many streams the process
+    # has made before (this test timed out in "round 1" in some orders of the suite and in none of others: round 2's
+    # gpurun_out/r2_stage2d.log, round 3's r3b_traj.log).  A stream with a compute-unit mask carries its own queue (the mask is
+    # a property of the queue), and the rank's own share of the units on top (dmf.xgmi.cu_share_stream).  Each stream also
+    # runs one trivial kernel to completion before the first exchange (queue creation does not happen beside a spinning kernel).
+    from dmf import xgmi
+    streams = [xgmi.cu_share_stream(r, world) for r in range(world)]
     for st in streams:
         with torch.cuda.stream(st):
             torch.zeros(64, device='cuda').add_(1.0)
