@@ -374,10 +374,10 @@ __global__ __launch_bounds__(320) void grad_reduce_kernel(const float* __restric
       g = tree16(t);
     }
   }
-  if (a.x.world > 1) {                               // block-uniform: every thread takes part in the barriers
+  if (a.x.world > 1) {                               // (the owning lanes exchange; no barriers inside)
     const int seq = *a.step_dev + a.seq_bias;
-    g = xgmi_exchange(a.x, 0, seq, blockIdx.x, p, own, g) * a.grad_scale;
-    if (kind < 2 && n0 == 0) g2 = xgmi_exchange(a.x, 0, seq, nTotal + blockIdx.x, p2, own2, g2) * a.grad_scale;
+    g = xgmi_exchange(a.x, 0, seq, p, own, g) * a.grad_scale;
+    if (kind < 2 && n0 == 0) g2 = xgmi_exchange(a.x, 0, seq, p2, own2, g2) * a.grad_scale;
   }
   if (own) adam_apply(a, p, g, th0, m_0, v_0, bcs);
   if (own2) adam_apply(a, p2, g2, th2, m_2, v_2, bcs);
@@ -802,11 +802,10 @@ static int fill_xgmi(const dmf_xgmi_comm* c, XgmiDev& x) {
   if (c->capacity <= 0) return fail("%s", "bad xgmi capacity");
   x.world = c->world; x.rank = c->rank;
   x.cap = (c->capacity + 255) / 256 * 256;
-  x.nblk = xgmi_nblk(x.cap);
   x.timeout_ticks = (int64_t)(c->timeout_ms > 0 ? c->timeout_ms : 20000) * 100000;   // wall_clock64 runs at 100 MHz
   for (int r = 0; r < c->world; ++r) {
     if (c->data[r] == nullptr || c->flags[r] == nullptr) return fail("%s", "xgmi peer buffer missing");
-    x.data[r] = static_cast<float*>(c->data[r]);
+    x.data[r] = static_cast<unsigned long long*>(c->data[r]);
     x.flags[r] = static_cast<int32_t*>(c->flags[r]);
   }
   return 0;
@@ -853,8 +852,6 @@ static int run_reduce(const dmf_shape* s, int32_t B, const void* workspace, floa
   const int nAttn = L.attention ? (a.ASLAB + 63) / 64 : 0;
   if (nFc1 > 0xffff || nFc2 > 0xffff || nConv > 0xffff || nAttn > 0x7fff) return fail("%s", "grad_reduce: too many blocks of one kind");
   const int grid = nFc1 + nFc2 + nConv + nAttn + 1;   // + the bookkeeping block
-  // (the exchange keeps one flag per block; the bias sums of the first-column tiles use a second flag index behind the grid's)
-  if (comm != nullptr && 2 * grid > a.x.nblk) return fail("%s", "xgmi communicator has fewer block flags than the reduce grid needs");
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(grid), dim3(320), 0, static_cast<hipStream_t>(stream), a.slab, a.dh, a.z, a.dl, a.h,
                      nFc1 | (t1n << 16), nFc2 | (t2n << 16), nConv | (nAttn << 16), B, a);
   return check(hipGetLastError(), "grad_reduce launch");
@@ -917,8 +914,8 @@ int32_t dmf_xgmi_sizes(int64_t capacity, int32_t world, int64_t* data_bytes, int
   if (capacity <= 0 || world < 1 || world > XGMI_MAX || data_bytes == nullptr || flag_bytes == nullptr)
     return fail("%s", "bad xgmi_sizes argument");
   const int64_t cap = (capacity + 255) / 256 * 256;
-  *data_bytes = 4 * cap * world * (int64_t)sizeof(float);      // inbox: [region 2][parity 2][src world][cap]
-  *flag_bytes = (xgmi_status_index(world, xgmi_nblk(cap)) + 16) * (int64_t)sizeof(int32_t);
+  *data_bytes = 4 * cap * world * (int64_t)sizeof(unsigned long long);   // inbox: [region 2][parity 2][src world][cap] tagged words
+  *flag_bytes = 16 * (int64_t)sizeof(int32_t);                           // the status word (+ spare)
   return 0;
 }
 
@@ -959,14 +956,14 @@ int32_t dmf_xgmi_status(const dmf_xgmi_comm* c, int32_t* status) {
   XgmiDev x{};
   if (fill_xgmi(c, x)) return 1;
   if (check(hipDeviceSynchronize(), "hipDeviceSynchronize")) return 1;
-  return check(hipMemcpy(status, x.flags[x.rank] + xgmi_status_index(x.world, x.nblk), sizeof(int32_t), hipMemcpyDeviceToHost),
+  return check(hipMemcpy(status, x.flags[x.rank], sizeof(int32_t), hipMemcpyDeviceToHost),
                "hipMemcpy(status)");
 }
 
 __global__ __launch_bounds__(256) void xgmi_allreduce_kernel(const XgmiDev x, float* buf, int64_t n, int seq) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < n;
-  const float s = xgmi_exchange(x, 1, seq, blockIdx.x, i, valid, valid ? buf[i] : 0.f);
+  const float s = xgmi_exchange(x, 1, seq, i, valid, valid ? buf[i] : 0.f);
   if (valid) buf[i] = s;
 }
 

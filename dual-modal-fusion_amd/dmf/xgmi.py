@@ -1,7 +1,8 @@
 """One-shot gradient exchange between the per-GPU processes of a node (include/dmf.h "dmf_xgmi_*").
 
-Each rank owns two uncached device buffers (gradient inbox, arrival flags) and maps every peer's pair
-through HIP IPC; the 64-byte handles travel over the torch.distributed group that already exists for the job.
+Each rank owns two uncached device buffers (the inbox of tagged words — value + sequence number in one 8-byte store — and
+a status block) and maps every peer's pair through HIP IPC; the 64-byte handles travel over the torch.distributed group that
+already exists for the job.
 `create()` verifies the mapping with a known-answer all-reduce against the group's own all_reduce before the
 communicator is handed out; if any rank cannot set it up (IPC refused, a wait timed out, a sum differs) every
 rank gets None and the caller stays on the RCCL all-reduce path.

@@ -246,8 +246,9 @@ int32_t dmf_band_mean(const float* x, int32_t layout, int64_t n_img, int64_t n_p
  * The reference has no multi-GPU path (BaseSolver builds one loader on one device, basesolver.py:86-105); the
  * coupling between data-parallel ranks is the parameter update of mainsolver.py:54-55 only.  One-shot exchange
  * for the sub-MB gradient: every rank writes its local gradient into an inbox slot in EVERY rank's uncached device
- * buffer over xGMI, raises a per-block flag on every peer, and each rank then adds the values in its own inbox in
- * rank order (same bits on every rank, no atomics), inside the gradient-reduce + Adam launch.  Buffers are shared
+ * buffer over xGMI — each value together with its sequence number in ONE 8-byte store, so the value is its own
+ * arrival mark — and each rank then polls its own inbox and adds the values in rank order (same bits on every
+ * rank, no atomics), inside the gradient-reduce + Adam launch.  Buffers are shared
  * between the per-GPU processes with HIP IPC handles; the caller moves the 64-byte handles between ranks (any
  * host channel: torch.distributed all_gather_object, a file, a pipe).  Everything is device-side, so a whole
  * data-parallel step can be captured in a hipGraph. */
@@ -259,7 +260,7 @@ typedef struct dmf_xgmi_comm {
   int32_t seq_bias;       /* added to the device step count to form the exchange sequence number; the host  */
                           /* raises it whenever it rewinds the device step count (graph warm-up)            */
   void* data[DMF_XGMI_MAX_RANKS];    /* data[r]: rank r's inbox (own allocation or IPC mapping)             */
-  void* flags[DMF_XGMI_MAX_RANKS];   /* flags[r]: rank r's flag block                                       */
+  void* flags[DMF_XGMI_MAX_RANKS];   /* flags[r]: rank r's status block (only the owner's is used)          */
 } dmf_xgmi_comm;
 int32_t dmf_xgmi_sizes(int64_t capacity, int32_t world, int64_t* data_bytes, int64_t* flag_bytes);
 int32_t dmf_xgmi_alloc(int64_t bytes, void** ptr);          /* uncached device memory, zero-filled (host sync) */
