@@ -331,6 +331,37 @@ def test_xgmi_protocol_many_ranks_one_process(world):
             lib.xgmi_free(d); lib.xgmi_free(f)
 
 
+def test_xgmi_wait_is_bounded_and_sticky():
+    """A peer that never arrives: the waiting lanes give up after timeout_ms, the communicator's status turns 1 and stays 1,
+    and later exchanges on it return without waiting (a stuck peer must cost one time-out, not one per step) — the exit
+    condition every wave of the exchange reaches."""
+    import time
+    sys.path[:0] = [PKG, REPO]
+    from dmf import lib
+    cap, world = 1000, 2
+    data_bytes, flag_bytes = lib.xgmi_sizes(cap, world)
+    bufs = [(lib.xgmi_alloc(data_bytes), lib.xgmi_alloc(flag_bytes)) for _ in range(world)]
+    c = lib.XgmiComm(world=world, rank=0, capacity=cap, timeout_ms=200, seq_bias=0)
+    for q in range(world):
+        c.data[q], c.flags[q] = bufs[q]
+    try:
+        v = torch.ones(cap, device='cuda')
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lib.xgmi_allreduce(c, v, cap, 1)                      # rank 1 never runs
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        assert lib.xgmi_status(c) == 1
+        assert 0.15 < t1 - t0 < 2.0, 'the wait took %.3f s for a 0.2 s time-out' % (t1 - t0)
+        lib.xgmi_allreduce(c, v, cap, 2)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t1 < 0.1 and lib.xgmi_status(c) == 1
+    finally:
+        torch.cuda.synchronize()
+        for d, f in bufs:
+            lib.xgmi_free(d); lib.xgmi_free(f)
+
+
 # ---------------------------------------------------------------------------------------------- stage 2, data parallel
 QCFG = {'patch_size': 5, 'Categories_Number': 5, 'data_city': 's', 'DATA_DICT': {'s': {'size': [20, 20, 4]}},
         'gmf': {'width': 40, 'single_input': 1}, 'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1}}
