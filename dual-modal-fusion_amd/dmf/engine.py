@@ -24,21 +24,6 @@ from . import lib
 _hip_graph_upload = None
 
 
-def _hip_runtime_of_torch():
-    """The libamdhip64 this process already has mapped (torch's own), found in /proc/self/maps — dlopen by bare name could
-    bind a second copy of the runtime, whose graph handles mean nothing to the first."""
-    import ctypes
-    try:
-        with open('/proc/self/maps') as f:
-            for line in f:
-                path = line.split(None, 5)[-1].strip() if line.count('/') else ''
-                if 'libamdhip64.so' in path:
-                    return ctypes.CDLL(path)
-    except OSError:
-        pass
-    return None
-
-
 def _upload_graph(g):
     """hipGraphUpload of a freshly captured graph: its first replay otherwise pays the upload (~20 us, measured with
     tools/graph_first.py) inside whatever the caller is timing.  Returns True when the upload happened; a missing symbol or a
@@ -46,7 +31,7 @@ def _upload_graph(g):
     global _hip_graph_upload
     import ctypes
     if _hip_graph_upload is None:
-        rt = _hip_runtime_of_torch()
+        rt = lib.hip_runtime_of_torch()
         fn = getattr(rt, 'hipGraphUpload', None) if rt is not None else None
         if fn is None:
             _hip_graph_upload = False

@@ -321,6 +321,20 @@ def grad_reduce_xgmi_adam(shape, B, ws, theta, m, v, comm, lr, b1, b2, eps, grad
                                          _ptr(loss_hist), _stream()))
 
 
+def hip_runtime_of_torch():
+    """The libamdhip64 this process already has mapped (torch's own), found in /proc/self/maps — dlopen by bare name could
+    bind a second copy of the runtime, whose stream and graph handles mean nothing to the first.  None if not found."""
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                path = line.split(None, 5)[-1].strip() if line.count('/') else ''
+                if 'libamdhip64.so' in path:
+                    return C.CDLL(path)
+    except OSError:
+        pass
+    return None
+
+
 def xgmi_sizes(capacity, world):
     d, f = C.c_int64(), C.c_int64()
     check(_lib.dmf_xgmi_sizes(capacity, world, C.byref(d), C.byref(f)))

@@ -77,7 +77,9 @@ def cu_share_stream(rank, world, device=None):
     rank's blocks are dispatched in order whatever the peers do, and all ranks work through the same block indices."""
     import ctypes
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    hip = ctypes.CDLL('libamdhip64.so')              # (the runtime torch has loaded)
+    hip = lib.hip_runtime_of_torch()                 # (the runtime torch has mapped, not a second copy by bare name)
+    if hip is None:
+        raise lib.DmfError('libamdhip64 is not mapped into this process')
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     lo, hi = rank * n_cu // world, (rank + 1) * n_cu // world
     words = (n_cu + 31) // 32
