@@ -360,7 +360,7 @@ class TrainEngine:
         """One replay of the captured graph that leaves no trace (weights, optimiser state, cursors and loss history are put
         back): the first launch of a graph executable pays one-time costs of the launch machinery, which belong to a
         warm-up.  bench.py calls it when the requested warm-up is shorter than one graph.  Single GPU only: under the
-        xGMI exchange a replay also advances the peers' inbox flags, which cannot be put back."""
+        xGMI exchange a replay also advances the sequence numbers in the peers' inboxes, which cannot be put back."""
         if self.graph is None or self.world != 1 or self.host_cursor + self.graph_steps > self.plan_steps:
             return False
         state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)

@@ -219,7 +219,7 @@ class Solver(BaseSolver):
                     xy, lab = self._xy_labels(batch)
                     # the evaluation launch's own per-patch cross-entropy (dmf_forward_ce) where the shape has it ...
                     part = self.eval_engine.ce_sum(xy.to(self.DEVICE), lab.to(self.DEVICE)) if hasattr(self.eval_engine, 'ce_sum') else None
-                    if part is None:                         # ... else torch's on the logits (attention network, generic kernel)
+                    if part is None:                         # ... else torch's on the logits (attention network)
                         logits, target, _, _ = self._forward_batch(batch)
                         part = ce(logits, target).double() * target.shape[0]
                     tot += part

@@ -96,7 +96,7 @@ int32_t dmf_forward(const dmf_shape* shape, const dmf_input* in, const float* th
                     float* logits, int32_t* pred, void* stream);
 /* The same launch with the per-patch cross-entropy against labels [B] int32 written to loss [B] — the validation pass,
  * `loss = self.loss(output, target.long())` under no_grad (mainsolver.py:62-76), by the training kernel's own formula.
- * Fails (use dmf_forward + the caller's loss) for shapes that run the generic kernel and for the attention network. */
+ * Fails (use dmf_forward_attn + the caller's loss) for the attention network. */
 int32_t dmf_forward_ce(const dmf_shape* shape, const dmf_input* in, const float* theta, const float* pool_w,
                        const int32_t* labels, float* logits, float* loss, int32_t* pred, void* stream);
 

@@ -5,7 +5,7 @@ dmf_grad_reduce -> all-reduce(sum) of ONE flat gradient -> dmf_adam_step(grad_sc
 
 The same check runs over the one-shot xGMI exchange (dmf_grad_reduce_xgmi_adam, HIP-IPC mapped peer buffers) with 2, 3 and
 4 ranks, stepping eagerly and replaying a captured hipGraph of the whole data-parallel step; on the one-GPU box the "peers"
-are processes on the same device, which exercises the IPC mapping, flags, parities and the rank-ordered sum, not the xGMI
+are processes on the same device, which exercises the IPC mapping, tagged words, parities and the rank-ordered sum, not the xGMI
 links themselves.  The exchange makes a kernel wait for a kernel of ANOTHER process.  With three and more processes on ONE
 GPU that dead-locks on residency (measured in round 3: the ranks that reach the exchange first fill every compute unit with
 waiting blocks and the last rank's kernels find no unit), so each rank of those cases launches on a stream that owns a
@@ -278,9 +278,9 @@ def test_solver_data_parallel_equals_single_rank():
 
 @pytest.mark.parametrize('world', [3, 4])      # (streams beyond the device's concurrent hardware queues would serialise and wait for ever)
 def test_xgmi_protocol_many_ranks_one_process(world):
-    """The exchange protocol itself (slots, parities, flags, sequence numbers, rank-ordered sum) for more than two ranks,
+    """The exchange protocol itself (slots, parities, tagged words, sequence numbers, rank-ordered sum) for more than two ranks,
     made deterministic on a one-GPU box: the `world` ranks are `world` STREAMS of this process (kernels of one process do
-    run side by side), each with its own owner-uncached inbox and flags; 12 rounds reuse every parity slot six times and
+    run side by side), each with its own owner-uncached inbox and status block; 12 rounds reuse every parity slot six times and
     the vector length changes from round to round.  What this cannot cover — the IPC mapping and real xGMI links — is what
     the multi-process cases above and bench.py's warm-up admission check are for."""
     sys.path[:0] = [PKG, REPO]
