@@ -167,7 +167,7 @@ class TrainEngine:
                 lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
                                   adam_step_dev=dev_step)
             lib.grad_reduce(self.shape, nB, self.ws, self.grad)
-            if self.world > 1:
+            if not self._single():
                 import torch.distributed as dist
                 dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
             if loss_hist is not None:
@@ -183,7 +183,7 @@ class TrainEngine:
             sc = self.scaler
             lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
                               adam_step_dev=dev_step, scaler_state=sc.state)
-            if self.world == 1:                          # three launches: patch kernel, reduce (+ unscale + check), Adam-or-skip
+            if self._single():                          # three launches: patch kernel, reduce (+ unscale + check), Adam-or-skip
                 lib.grad_reduce_scaled(self.shape, nB, self.ws, self.grad, sc.state, cursor_dev=dev_cursor,
                                        loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
                 lib.unscale_adam(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, sc.state,
@@ -204,7 +204,7 @@ class TrainEngine:
         else:
             lib.train_fwd_bwd(self.shape, inp, theta, self.net.pool_w, labels, 1.0 / nB, self.logits, self.loss, self.ws,
                               adam_step_dev=dev_step)
-        if self.world == 1:
+        if self._single():
             lib.grad_reduce_adam(self.shape, nB, self.ws, theta, self.m, self.v, None, self.lr, self.b1, self.b2, self.eps,
                                  self.step_count, adam_step_dev=dev_step, cursor_dev=dev_cursor,
                                  loss=self.loss if loss_hist is not None else None, loss_hist=loss_hist)
@@ -216,6 +216,8 @@ class TrainEngine:
             import torch.distributed as dist
             lib.grad_reduce(self.shape, nB, self.ws, self.grad)
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if loss_hist is not None:                    # (this rank's mean loss of the step, as the fused forms record it)
+                loss_hist.scatter_(0, dev_cursor.long(), self.loss[:nB].mean().reshape(1))
             lib.adam_step(theta, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self.step_count,
                           grad_scale=1.0 / self.world, adam_step_dev=dev_step, cursor_dev=dev_cursor)
 
@@ -287,7 +289,7 @@ class TrainEngine:
                 try:
                     self._capture(steps_per_graph)
                 except RuntimeError:
-                    if self.world == 1 or self.comm is not None:
+                    if self._single() or self.comm is not None:
                         raise
                     # RCCL's all-reduce refused to be captured (every rank runs the same software, so every rank lands
                     # here): stay on eager launches for the rest of this engine's life
@@ -304,15 +306,20 @@ class TrainEngine:
             self._plan_step()
         return steps
 
+    def _single(self):
+        """One rank and no collective in the step.  `_force_collective` (tests only) keeps the group's all-reduce in the step of
+        a ONE-rank group, so that the RCCL form of the step — eager and captured in a hipGraph — runs on a one-GPU box."""
+        return self.world == 1 and not getattr(self, '_force_collective', False)
+
     def _native_loop_ok(self):
         """run_plan(steps, steps_per_graph=-1): the C loop of dmf_train_plan_steps — late-fusion net, ADAM, one GPU, no scaler."""
-        return self.world == 1 and self.scaler is None and self.optim == 'ADAM' and not self.shape.attention
+        return self._single() and self.scaler is None and self.optim == 'ADAM' and not self.shape.attention
 
     def _graphable(self):
         """Can a step be captured in a hipGraph?  One GPU: yes.  The one-shot exchange: yes (it is part of the reduce launch).
         The RCCL all-reduce: yes when the process group is RCCL — its collectives are capturable, and a host-enqueued
         all_reduce of 32 KB per ~16-us step would otherwise bound the step by the host (DMF_RCCL_GRAPH=0 switches this off)."""
-        if self.world == 1 or self.comm is not None:
+        if self._single() or self.comm is not None:
             return True
         if self.scaler is not None or self.optim != 'ADAM' or not getattr(self, '_rccl_graph', True):
             return False
@@ -361,7 +368,7 @@ class TrainEngine:
         back): the first launch of a graph executable pays one-time costs of the launch machinery, which belong to a
         warm-up.  bench.py calls it when the requested warm-up is shorter than one graph.  Single GPU only: under the
         xGMI exchange a replay also advances the sequence numbers in the peers' inboxes, which cannot be put back."""
-        if self.graph is None or self.world != 1 or self.host_cursor + self.graph_steps > self.plan_steps:
+        if self.graph is None or not self._single() or self.host_cursor + self.graph_steps > self.plan_steps:
             return False
         state = (self.theta, self.m, self.v, self.dev_step, self.dev_cursor, self.loss_hist)
         if self.scaler is not None:

@@ -331,6 +331,52 @@ def test_xgmi_protocol_many_ranks_one_process(world):
             lib.xgmi_free(d); lib.xgmi_free(f)
 
 
+def _train_rccl_one_rank(rank, world, port, q, graph_steps):
+    import datetime
+    import torch.distributed as dist
+    MS, PAN, xy, lab = _problem(48 * 6)
+    from dmf.engine import Scene, TrainEngine
+    from model.gmfnet import Net
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=60), device_id=torch.device('cuda', 0))
+    out = {}
+    for forced in (False, True):
+        torch.manual_seed(0)
+        net = Net(CFG).to('cuda:0')
+        eng = TrainEngine(net, Scene(MS, PAN, 'cuda:0'), 48, lr=1e-2, process_group=dist.group.WORLD)
+        eng._force_collective = forced         # True: dmf_grad_reduce -> RCCL all-reduce -> dmf_adam_step, as with N ranks
+        eng.load_plan(xy, lab)
+        if graph_steps:
+            assert eng._graphable()
+            eng.run_plan(1, 0)
+            eng.run_plan(4, graph_steps)
+            assert (eng.graph is not None) or not forced or not getattr(eng, '_rccl_graph', True)
+            out['captured_%d' % forced] = eng.graph is not None
+            eng.run_plan(1, 0)
+        else:
+            eng.run_plan(6, 0)
+        torch.cuda.synchronize()
+        out[forced] = (eng.theta.cpu().numpy(), eng.mean_losses().numpy())
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('graph_steps', [0, 2])
+def test_rccl_form_of_the_step_on_a_one_rank_group(graph_steps):
+    """The fallback of the data-parallel step — dmf_grad_reduce, the process group's all-reduce (RCCL), dmf_adam_step — run on
+    a ONE-rank NCCL group, eagerly and captured in a hipGraph (TrainEngine._graphable: RCCL collectives are capturable),
+    against the fused single-GPU step on the same batches.  One rank is all a one-GPU box can give RCCL; what this covers is
+    the process-group plumbing, the capture and replay of the collective inside the step's graph and the unfused ADAM."""
+    out = _run_ranks(_train_rccl_one_rank, 1, (graph_steps,))
+    (th0, l0), (th1, l1) = out[False], out[True]
+    print('RCCL form vs fused step: parameters max abs diff %.2e, losses %.2e; graph captured: %s'
+          % (np.abs(th0 - th1).max(), np.abs(l0 - l1).max(), out.get('captured_1')))
+    assert np.abs(th0 - th1).max() < 2e-6 and np.abs(l0 - l1).max() < 1e-6
+    if graph_steps:
+        assert out['captured_1'], 'the all-reduce was not captured in the step graph (eager fallback taken)'
+
+
 def test_xgmi_wait_is_bounded_and_sticky():
     """A peer that never arrives: the waiting lanes give up after timeout_ms, the communicator's status turns 1 and stays 1,
     and later exchanges on it return without waiting (a stuck peer must cost one time-out, not one per step) — the exit
