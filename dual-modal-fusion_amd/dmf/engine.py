@@ -792,16 +792,61 @@ class QuaEvalEngine:
         self.loss = torch.zeros(1, device=dev)
         self.params = lib.qua_params(dqtl) if dqtl is not None else None
 
-    def _forward(self, xy, streams):
+    def _forward(self, xy, streams, checked=False):
         n = int(xy.shape[0])
         if n > self.B:
             raise lib.DmfError('batch larger than the engine was built for')
         dev = self.scene.device
-        xyk = self.scene.stack_xy(torch.as_tensor(xy).cpu(), streams).to(dev).contiguous()
-        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xyk.cpu().numpy())
+        if checked and torch.is_tensor(xy) and xy.device == dev:        # (whole-set passes: bounds checked once, stacking on the device)
+            off = torch.zeros(1, 2, dtype=torch.int32, device=dev)
+            parts = []
+            for k in range(streams):
+                off[0, 0] = k * self.scene.Hp
+                parts.append(xy + off)
+            xyk = torch.cat(parts).contiguous()
+        else:
+            xyk = self.scene.stack_xy(torch.as_tensor(xy).cpu(), streams).to(dev).contiguous()
+            lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, xyk.cpu().numpy())
         inp = lib.input_gather(self.shape, self.scene.A, self.scene.B, xyk)
         lib.forward(self.shape, inp, self.net.flat_parameters(), self.net.pool_w, self.logits)
         return n
+
+    def _checked_all(self, xy_all):
+        dev = self.scene.device
+        xy_all = torch.as_tensor(xy_all).to(torch.int32)
+        host = xy_all.cpu()
+        lib.check_xy_bounds(self.shape, self.scene.A, self.scene.B, self.scene.stack_xy(host, 2).numpy())
+        return xy_all.to(dev).contiguous(), host.numpy()
+
+    def confusion(self, xy_all, labels_all, matrix=None):
+        """Confusion matrix [K,K] int64 (rows = prediction) of the pair prediction over all given pixels, in chunks of the
+        engine's size (tostagesolver.py:331-341)."""
+        dev = self.scene.device
+        K = self.net.arch['K']
+        xy_all, _ = self._checked_all(xy_all)
+        labels_all = torch.as_tensor(labels_all).to(device=dev, dtype=torch.int32).contiguous()
+        if matrix is None:
+            matrix = torch.zeros(K, K, dtype=torch.int64, device=dev)
+        for i in range(0, xy_all.shape[0], self.B):
+            n = self._forward(xy_all[i:i + self.B], 2, checked=True)
+            lib.pair_argmax(self.logits, n, self.pred)
+            lib.confusion_accum(self.pred[:n], labels_all[i:i + n], K, matrix)
+        return matrix
+
+    def label_map(self, xy_all, H, W, label_map=None):
+        """Pair prediction of every given pixel written at (x, y) of an [H, W] int32 map (tostagesolver.py:360-383)."""
+        dev = self.scene.device
+        xy_all, host = self._checked_all(xy_all)
+        if len(host) and (int(host[:, 0].max()) >= H or int(host[:, 1].max()) >= W):
+            raise lib.DmfError('pixel outside the %d x %d label map' % (H, W))
+        if label_map is None:
+            label_map = torch.zeros(H, W, dtype=torch.int32, device=dev)
+        for i in range(0, xy_all.shape[0], self.B):
+            xy = xy_all[i:i + self.B]
+            n = self._forward(xy, 2, checked=True)
+            lib.pair_argmax(self.logits, n, self.pred)
+            lib.labelmap_write(self.pred[:n], xy, W, label_map)
+        return label_map
 
     def predict(self, xy):
         n = self._forward(xy, 2)

@@ -80,8 +80,9 @@ class toStageSolver(Solver):
 
     def _make_eval_engine(self):
         from dmf.engine import QuaEvalEngine
+        # (evaluation chunks of the engine's own size, as in Solver._eval_chunk: the configured sizes belong to the host-fed loader)
         self.eval_engine = QuaEvalEngine(self.cur_model, self.qua_scene,
-                                         max(self.cfg['test_batchsize'], self.cfg['color_batchsize']), self.cfg['dqtl'])
+                                         max(self.cfg['test_batchsize'], self.cfg['color_batchsize'], 8192), self.cfg['dqtl'])
 
     def _train_epoch_fast(self):
         eng, B = self.engine, self.cfg['batchsize']
@@ -167,9 +168,13 @@ class toStageSolver(Solver):
         K = self.cfg['Categories_Number']
         matrix = torch.zeros(K, K, dtype=torch.int64, device=self.DEVICE)
         with torch.no_grad():
-            for batch in (self.test_index_loader if self.fast else self.test_loader):     # every batch (:331-341)
-                pred, target, _ = self._pair_pred(batch)
-                lib.confusion_accum(pred, target.contiguous(), K, matrix)
+            if self.fast:                                    # the whole split in the engine's own chunks
+                parts = [self._xy_labels(b) for b in self.test_index_loader]
+                matrix = self.eval_engine.confusion(torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), matrix)
+            else:
+                for batch in self.test_loader:               # every batch (:331-341)
+                    pred, target, _ = self._pair_pred(batch)
+                    lib.confusion_accum(pred, target.contiguous(), K, matrix)
         self.test_time = time.time() - time1
         self.test_matrix = matrix.cpu().numpy().astype(np.float64)
         self.indicator()
@@ -187,8 +192,10 @@ class toStageSolver(Solver):
             for use, loaders in ((self.cfg['color']['supervised'], (self.color_index_loader1, self.color_loader1)),
                                  (self.cfg['color']['unsupervised'], (self.color_index_loader2, self.color_loader2))):
                 m = torch.zeros(H, W, dtype=torch.int32, device=self.DEVICE)
-                if use:
-                    for batch in loaders[0 if self.fast else 1]:
+                if use and self.fast:
+                    m = self.eval_engine.label_map(torch.cat([self._xy_labels(b)[0] for b in loaders[0]]), H, W, m)
+                elif use:
+                    for batch in loaders[1]:
                         pred, _, xy = self._pair_pred(batch)
                         lib.labelmap_write(pred, xy.to(self.DEVICE).contiguous(), W, m)
                 maps.append(m.cpu().numpy())

@@ -2,6 +2,7 @@
 and .confusion over all pixels of a synthetic scene, for several evaluation chunk sizes.
 
     python tools/eval_bench.py [size] [bands] [aux_bands] [width]      default: 512 224 3 32 (BASELINE configs[3] scene)
+    python tools/eval_bench.py qua [size]                              stage 2: pair prediction over four 4-band streams, 16x16 patches
 """
 import os
 import sys
@@ -18,7 +19,38 @@ from function.function import data_padding, data_padding_aux
 from model.gmfnet import Net
 
 
+def main_qua():
+    from dmf.engine import QuaEvalEngine, QuaScene
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    cfg = {'patch_size': 16, 'Categories_Number': 12, 'data_city': 's', 'DATA_DICT': {'s': {'size': [size, size, 4]}},
+           'gmf': {'width': 40, 'single_input': 1}, 'dqtl': {'alpha': 0.1, 'beta': 0.05, 'gamma': 1.0, 'epsilon': 1e-8, 'tao': 0.1}}
+    ms, pan, label = synth.make_scene(size, size, 4, 1, 1, n_classes=11, seed=0)
+    g = np.random.default_rng(1)
+    scenes = [data_padding(x, cfg, 'ms') for x in (ms, ms[::-1].copy(), ms + 0.1 * g.standard_normal(ms.shape), ms * 0.5)]
+    torch.manual_seed(0)
+    net = Net(cfg).cuda()
+    scene = QuaScene(scenes, 'cuda:0')
+    xx, yy = np.meshgrid(np.arange(size), np.arange(size), indexing='ij')
+    xy = torch.from_numpy(np.stack([xx.reshape(-1), yy.reshape(-1)], 1).astype(np.int32))
+    n = xy.shape[0]
+    ref_map = None
+    for B in (256, 2048, 8192):
+        ev = QuaEvalEngine(net, scene, B, cfg['dqtl'])
+        ev.label_map(xy[:B], size, size)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lm = ev.label_map(xy, size, size)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if ref_map is None:
+            ref_map = lm.clone()
+        print('stage 2, chunk %5d: class map of %d pixels (2 streams each) %.2f ms (%.1f M pixels/s); map identical to chunk 256: %s'
+              % (B, n, (t1 - t0) * 1e3, n / (t1 - t0) / 1e6, bool(torch.equal(lm, ref_map))), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'qua':
+        return main_qua()
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     C = int(sys.argv[2]) if len(sys.argv) > 2 else 224
     C2 = int(sys.argv[3]) if len(sys.argv) > 3 else 3
