@@ -16,7 +16,7 @@ from torch.utils.data import DataLoader, Subset
 
 from function.function import data_padding, data_padding_aux, data_show, label_mat2np, read_tif, split_data, split_data_old
 from indicators.kappa import aa_oa, expo_result
-from train.dataset import dataset_dual
+from train.dataset import collate_batched, dataset_dual
 
 
 class BaseSolver:
@@ -66,7 +66,7 @@ class BaseSolver:
     def _loader(self, subset, batch, shuffle):
         twin = Subset(self.index_dataset, indices=subset.indices)
         return (DataLoader(dataset=subset, batch_size=batch, shuffle=shuffle, num_workers=self.num_workers),
-                DataLoader(dataset=twin, batch_size=batch, shuffle=shuffle, num_workers=0))
+                DataLoader(dataset=twin, batch_size=batch, shuffle=shuffle, num_workers=0, collate_fn=collate_batched))
 
     def dataloader(self):
         cfg = self.cfg

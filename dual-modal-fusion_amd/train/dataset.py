@@ -47,8 +47,20 @@ class _IndexView(Dataset):
     def __getitem__(self, index):
         return int(self.x[index]), int(self.y[index]), int(self.label[index]), int(index)
 
+    def __getitems__(self, indices):
+        """A whole batch at once, already collated (the loader twins pass it through: `collate_batched`): what the default
+        collate makes of `[self[i] for i in indices]` — four int64 vectors — without a Python tuple per pixel (a 512x512 scene
+        has 262,144 of them per epoch; the sampler, and with it the global RNG stream, is untouched)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        return (torch.from_numpy(self.x[idx]), torch.from_numpy(self.y[idx]), torch.from_numpy(self.label[idx]), torch.from_numpy(idx))
+
     def __len__(self):
         return len(self.x)
+
+
+def collate_batched(batch):
+    """collate_fn of the index loaders: `_IndexView.__getitems__` has collated already."""
+    return batch
 
 
 class dataset_qua_dqtl(Dataset):
