@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "dmf_kargs.h"
 
@@ -189,11 +190,32 @@ struct AttnTrainLds {
   static_assert(BYTES <= 160 * 1024, "one workgroup per CU");
 };
 
+// LDS of the forward-only kernel (TRAIN = false): what inference needs and nothing else — token maps, K as rows, V transposed,
+// one head's Wq / Wk / Wv / Wo, the head's vectors — 77,888 bytes, so that TWO workgroups share a CU (4 waves per SIMD at its
+// ~120 registers) and each covers the other's barrier waits and LDS round trips.  Q needs no image at all: formed as
+// C[d][token] (operands swapped), the accumulators ARE the B operand of S^T = K Q^T for the wave's own queries; K is formed as
+// C[d][token] too and stored as rows [token][d] eight bytes at a time (its row-fragment reads pair with that operand's k order:
+// frag2).  Names the training code refers to exist with offset 0 and are never touched.
+template <class Sh, int E, int NH>
+struct AttnFwdLds {
+  static constexpr int T = 128, FP = 64, DH = 32, FO = 48;
+  static constexpr int VS = 136, QS = 48, KS = 48, WS = 80, OS = 40;
+  static constexpr int oTaT = 0, oTbT = oTaT + FP * VS, oK = oTbT + FP * VS, oVt = oK + T * KS, oWq = oVt + DH * VS,
+                       oWk = oWq + DH * WS, oWv = oWk + DH * WS, oWo = oWv + DH * WS, HALVES = oWo + FO * OS;
+  static constexpr int oQ = 0, oQt = 0, oKt = 0, oWqT = 0, oWkT = 0, oDhi = 0, oDlo = 0;                 // (training only)
+  static constexpr int fZ = 0, fHd = fZ + 80, fLg = fHd + 64, fPw = fLg + 64, fDzw = fPw + T, FLOATS = fDzw + 8 * FO;
+  static constexpr int fDl = 0, fDh = 0, fDz = 0, fU = 0, fOb = 0, fObw = 0, fSt = 0, fA = 0, fCw = 0, fC = 0, fG = 0;   // (training only)
+  static constexpr int WPREP = AttnTrainLds<Sh, E, NH>::WPREP;
+  static constexpr size_t BYTES = (size_t)HALVES * 2 + (size_t)FLOATS * 4;
+  static_assert(HALVES % 8 == 0 && oWq % 8 == 0 && oWo % 8 == 0, "16-byte aligned blocks");
+  static_assert(2 * BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
 // TRAIN = false: forward only (logits, argmax) — the inference / evaluation kernel of the attention network.
 template <class Sh, int E, int NH, bool TRAIN>
 __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) {
   using namespace at;
-  using L = AttnTrainLds<Sh, E, NH>;
+  using L = typename std::conditional<TRAIN, AttnTrainLds<Sh, E, NH>, AttnFwdLds<Sh, E, NH>>::type;
   constexpr int T = L::T, FP = L::FP, DH = L::DH, FO = L::FO, NT = 512;
   constexpr int VS = L::VS, QS = L::QS, KS = L::KS, WS = L::WS, OS = L::OS;
   constexpr int F = Sh::F, F2 = Sh::F2, H = Sh::H, P2 = Sh::P2;
@@ -299,10 +321,43 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
       (void)bwd;
       const uint4* src = reinterpret_cast<const uint4*>(a.wprep + (size_t)h * L::WPREP);
       uint4* dst = reinterpret_cast<uint4*>(sWq);
-      for (int i = tid; i < L::WPREP / 8; i += NT) dst[i] = src[i];
+      if constexpr (TRAIN) {
+        for (int i = tid; i < L::WPREP / 8; i += NT) dst[i] = src[i];
+      } else {                                         // [Wq | Wk | Wv] and, behind WqT / WkT in the global block, Wo
+        constexpr int N1 = 3 * DH * WS / 8, N2 = FO * OS / 8, SK = (3 * DH * WS + 2 * FO * OS) / 8;
+        for (int i = tid; i < N1 + N2; i += NT) dst[i] = src[i < N1 ? i : SK + (i - N1)];
+      }
     };
     // projections of the wave's 16 tokens; writes Qs (both layouts), K (both layouts), V^T
+    bf16x8 fq_own;                                     // forward-only kernel: bf16(Q scale)^T of the own queries as an MFMA operand
     auto project = [&](int lane, int g, int col, int hb) {         // hb >= 0: backward of head hb, also forms a_j
+      if constexpr (!TRAIN) {
+        // Q and K as C[d = 16n + 4g + r][token m0 + col] (weights as the A operand), V as C[token][d]: every LDS store of
+        // the forward is an 8-byte store and Q never leaves the registers
+        f32x4 qT[2], kT[2], v[2];
+  #pragma unroll
+        for (int n = 0; n < 2; ++n) qT[n] = kT[n] = v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int ks = 0; ks < FP / 32; ++ks) {
+          const bf16x8 fa = frag_t<VS>(sTaT, m0, 32 * ks, lane);
+          const bf16x8 fb = frag_t<VS>(sTbT, m0, 32 * ks, lane);
+  #pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            qT[n] = AT_MFMA(frag<WS>(sWq, 16 * n, 32 * ks, lane), fa, qT[n]);
+            kT[n] = AT_MFMA(frag<WS>(sWk, 16 * n, 32 * ks, lane), fb, kT[n]);
+            v[n] = AT_MFMA(fb, frag<WS>(sWv, 16 * n, 32 * ks, lane), v[n]);
+          }
+        }
+  #pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          *reinterpret_cast<uint2*>(sK + (m0 + col) * KS + 16 * n + 4 * g) = make_uint2(pk2(kT[n][0], kT[n][1]), pk2(kT[n][2], kT[n][3]));
+          *reinterpret_cast<uint2*>(sVt + (16 * n + col) * VS + m0 + 4 * g) = make_uint2(pk2(v[n][0], v[n][1]), pk2(v[n][2], v[n][3]));
+        }
+        const f32x4 q0 = qT[0] * scale, q1 = qT[1] * scale;
+        fq_own = pack_bf(q0, q1);                      // k = d: {4g + r} and {16 + 4g + r}, the order frag2 reads K's rows in
+        (void)hb;
+        return;
+      }
       f32x4 q[2], k[2], v[2];
   #pragma unroll
       for (int n = 0; n < 2; ++n) q[n] = k[n] = v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -348,9 +403,14 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
     };
     // P^T for the wave's queries: s[i][r] = P[t = tq][j = 16i + 4g + r]  (fp32, keys >= P2 masked)
     auto softmax_T = [&](f32x4 (&s)[8], int lane, int g, float& mx_out, float& inv_out) {
-      const bf16x8 fq = frag<QS>(sQ, m0, 0, lane);
+      if constexpr (TRAIN) {
+        const bf16x8 fq = frag<QS>(sQ, m0, 0, lane);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag<KS>(sK, 16 * i, 0, lane), fq, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag<KS>(sK, 16 * i, 0, lane), fq, (f32x4{0.f, 0.f, 0.f, 0.f}));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = AT_MFMA(frag2<KS>(sK, 16 * i, 0, 16, lane), fq_own, (f32x4{0.f, 0.f, 0.f, 0.f}));
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -450,7 +510,7 @@ __global__ __launch_bounds__(512) void attn_train_kernel(const AttnTrainArgs a) 
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += sDzw[w * FO + tid];
       sZ[tid] += s;
-    } else if (tid >= 64 && tid < 64 + E) {
+    } else if (TRAIN && tid >= 64 && tid < 64 + E) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += sObw[w * E + tid - 64];
@@ -852,7 +912,7 @@ hipError_t attn_prep_launch(const float* theta, int64_t oWq, int64_t oWk, int64_
 template <class Sh, bool TRAIN>
 static hipError_t launch_attn_train(const AttnTrainArgs& a, int grid, hipStream_t st) {
   static LdsAttrOnce once;
-  constexpr size_t bytes = AttnTrainLds<Sh, 96, 3>::BYTES;
+  constexpr size_t bytes = std::conditional<TRAIN, AttnTrainLds<Sh, 96, 3>, AttnFwdLds<Sh, 96, 3>>::type::BYTES;
   static_assert(bytes <= 160 * 1024, "attention kernel LDS");
   hipError_t e = once.set(reinterpret_cast<const void*>(&attn_train_kernel<Sh, 96, 3, TRAIN>), (int)bytes);
   if (e != hipSuccess) return e;
