@@ -11,6 +11,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'dual-modal-fusion_amd')
 
 SHAPES = {
     # name: (C, C2, P, S, K)
@@ -25,6 +27,9 @@ SHAPES = {
     'hsi9': (200, 1, 9, 1, 17),
     'hsi7': (200, 1, 7, 1, 17),
     'hsi224p9': (224, 3, 9, 1, 17),
+    # NOT in the compiled table: added at build time from tests/extra_shapes.txt (build.py --shapes), see
+    # test_row_added_at_build_time
+    'extra7': (8, 1, 7, 1, 5),
 }
 
 
@@ -587,3 +592,37 @@ def test_forward_ce_matches_torch_cross_entropy(name):
     assert_close(logits, want_logits, 1e-5, 0, 'forward_ce logits[%s]' % name)
     assert_close(loss, want, 2e-5, 0, 'forward_ce loss[%s]' % name)
     assert abs(loss.double().sum().item() - want.double().sum().item()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- rows added at build time
+EXTRA_LIB = os.path.join(PKG, 'dmf', 'libdmf_hip_extra.so')
+
+
+if os.environ.get('DMF_TEST_EXTRA_ROW') == '1':        # (collected only in the child process of test_row_added_at_build_time)
+    @pytest.mark.parametrize('B', [1, 37, 300])
+    def test_extra_row_inner(B):
+        """On the library that holds the extra row: forward, gather + argmax, fused train step against the oracle."""
+        test_forward_patches('extra7', B)
+        test_train_fwd_bwd_grads('extra7', B)
+        if B == 1:
+            test_forward_gather_and_pred('extra7')
+
+
+def test_row_added_at_build_time():
+    """`build.py --shapes FILE` (missing 3: a shape outside the compiled table used to be a dead end): the stock
+    library refuses the 8-band / 7x7 shape by name, a library built with tests/extra_shapes.txt runs it, and forward, gather +
+    argmax and the fused train step's gradients agree with the oracle like every stock row."""
+    import subprocess
+    import sys
+    from dmf import lib
+    from model.gmfnet import Net as HipNet
+    with pytest.raises(lib.DmfError, match='no compiled kernel instance'):
+        HipNet(make_cfg('extra7')).to('cuda:0')(*[x.cuda() for x in rand_batch('extra7', 2)[:2]])
+    sys.path.insert(0, PKG)
+    import build as dmf_build
+    out = dmf_build.build(shapes=os.path.join(REPO, 'tests', 'extra_shapes.txt'), suffix='extra', verbose=False)
+    assert out == EXTRA_LIB and os.path.exists(out)
+    env = dict(os.environ, DMF_LIB=EXTRA_LIB, DMF_TEST_EXTRA_ROW='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'test_extra_row_inner', '-m', 'gpu',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '3 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
