@@ -208,6 +208,10 @@ def main():
     ap.add_argument('--half', type=int, default=None, choices=[0, 1],
                     help='fp16 primary scene + fp16 spec_a operands (fp32 accumulate) + device loss scaler; default: 1 for '
                          '--config 4 (BASELINE configs[4]: "fp16 mixed precision"), else 0 (the fp32 headline)')
+    ap.add_argument('--scaler', type=int, default=1, choices=[0, 1],
+                    help='with --half 1: 1 = the device loss scaler with GradScaler\'s rule (the reference\'s autocast + GradScaler '
+                         'semantics: a third launch per step); 0 = fp16 storage and spec_a operands only (every gradient is fp32 '
+                         'in this design, the scale has no numerical job)')
     ap.add_argument('--train-rate', type=float, default=0.10)
     ap.add_argument('--steps-per-graph', type=int, default=None,
                     help='steps per captured hipGraph; 0 = eager launches from Python; -1 = one C loop of launches (dmf_train_plan_steps). '
@@ -267,7 +271,7 @@ def main():
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     scene = Scene(MS, PAN, dev, half=bool(args.half))
-    scaler = lambda: LossScaler(dev) if args.half else None      # (GradScaler defaults: 65536, x2 / x0.5, every 2000)
+    scaler = lambda: LossScaler(dev) if (args.half and args.scaler) else None      # (GradScaler defaults: 65536, x2 / x0.5, every 2000)
     comm = None
     # N > 2 has only ever been exercised with all ranks on ONE GPU (tests/test_gpu_dp.py); the exchange is admitted per run
     # by the checks below and the RCCL all-reduce is the fallback
@@ -453,7 +457,7 @@ def main():
         'metric': 'training patches/sec + kappa, 11x11x200 HSI + 11x11x1 SAR, 1/2/4/8 MI355X',
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': K_steps, 'warmup': W_steps,
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': ('f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32')
+        'dtype': (('f16 scene + spec_a operands, f32 accumulate / gradients / Adam' + (', dynamic loss scale' if args.scaler else ', no loss scale')) if args.half else 'f32')
                  if not args.attention else 'f32 (attention operands bf16, f32 accumulate)', 'data': 'synthetic',
         'config': {'workload': '%s; %dx%d scene, %d + %d bands, %dx%d patches, %d logits, batch %d per GPU, fused HIP fwd+loss+bwd+Adam'
                                % (CONFIGS[args.config]['name'], args.size, args.size, C, C2, P, P, args.classes + 1, B),
@@ -588,7 +592,7 @@ def main_stage2(args, dev, pg=None, rank=0, world=1, backend='nccl'):
     net = Net(cfg).to(dev)
     init_state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     scene = QuaScene(scenes, dev, half=bool(args.half))
-    sc = LossScaler(dev) if (args.half and world == 1) else None        # GradScaler's defaults (tostagesolver.py:83-84)
+    sc = LossScaler(dev) if (args.half and args.scaler and world == 1) else None        # GradScaler's defaults (tostagesolver.py:83-84)
     eng = QuaTrainEngine(net, scene, bs, cfg['dqtl'], lr=1e-3, scaler=sc, process_group=pg)
     total = W_steps + K_steps
     xy = np.stack([g.integers(0, H, total * bs * world), g.integers(0, W, total * bs * world)], 1).astype(np.int32)
@@ -654,7 +658,7 @@ def main_stage2(args, dev, pg=None, rank=0, world=1, backend='nccl'):
         'metric': 'training patches/sec + kappa, 11x11x200 HSI + 11x11x1 SAR, 1/2/4/8 MI355X',
         'value': world * 4 * bs * K_steps / dt, 'unit': 'patches/s', 'n_gpus': world, 'steps': K_steps, 'warmup': W_steps,
         'ms_per_step': dt / K_steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f16 scene + spec_a operands, f32 accumulate / gradients / Adam, dynamic loss scale' if args.half else 'f32',
+        'dtype': ('f16 scene + spec_a operands, f32 accumulate / gradients / Adam' + (', dynamic loss scale' if args.scaler else ', no loss scale')) if args.half else 'f32',
         'data': 'synthetic',
         'config': {'workload': '%s; %dx%d patches, %d logits, bs %d (%d stacked patches per step), qua_loss, fused HIP step'
                                % (CONFIGS['4']['name'], P, P, args.classes + 1, bs, 4 * bs),
