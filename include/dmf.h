@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DMF_VERSION 200   /* 0.2.0: dmf_input.half, unit-gradient step, loss scaler, SGD / RMSprop steps (round 2) */
+#define DMF_VERSION 300   /* 0.3.0 (round 3): dmf_train_plan_steps, dmf_forward_ce, tagged-word exchange (dmf_xgmi_sizes grew), one patch kernel; 0.2.0: dmf_input.half, unit-gradient step, loss scaler, SGD / RMSprop steps */
 #define DMF_KMAX 64       /* max number of logits (Categories_Number, utils/config.py:25) */
 
 /* Network / patch geometry (oracle/gmfnet_ref.py::arch_from_cfg). */
